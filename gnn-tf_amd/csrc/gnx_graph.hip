@@ -1,0 +1,434 @@
+// Graph handle: COO -> sorted entries -> coalesced CSR (+ lazy transposed structure) on gfx950.
+// Replaces the tf.sparse.SparseTensor that gnntf's graph2adj returns
+// (reference gnntf/core/gnn/graph_manipulation.py:24-31) as the container of the adjacency.
+#include <cstring>
+#include <string.h>
+
+#include "gnx_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace gnx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// small RAII holder so early returns do not leak temporaries
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+    void *release() { void *q = p; p = nullptr; return q; }
+};
+
+static inline unsigned blocks_for(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+static unsigned bits_for(uint64_t max_key_exclusive) {
+    unsigned b = 1;
+    while (b < 64 && (max_key_exclusive >> b) != 0) ++b;
+    return b;
+}
+
+// ---- kernels ---------------------------------------------------------------------------
+__global__ void k_make_keys(const int64_t *__restrict__ indices, int64_t nnz, int64_t n_rows, int64_t n_cols,
+                            uint64_t *__restrict__ keys, int *__restrict__ bad) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    int64_t r = indices[2 * e], c = indices[2 * e + 1];
+    if (r < 0 || r >= n_rows || c < 0 || c >= n_cols) {
+        atomicExch(bad, 1);
+        r = 0; c = 0;
+    }
+    keys[e] = (uint64_t)r * (uint64_t)n_cols + (uint64_t)c;
+}
+
+__global__ void k_heads(const uint64_t *__restrict__ keys, int64_t nnz, int32_t *__restrict__ head) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    head[e] = (e == 0 || keys[e] != keys[e - 1]) ? 1 : 0;
+}
+
+// slot = inclusive_scan(head) - 1
+__global__ void k_fill_slots(const uint64_t *__restrict__ keys, const int32_t *__restrict__ scan, int64_t nnz,
+                             int64_t n_cols, int32_t *__restrict__ colidx, int32_t *__restrict__ rowidx,
+                             int64_t *__restrict__ slot_ptr /* may be null */) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const bool is_head = (e == 0) || (scan[e] != scan[e - 1]);
+    if (!is_head) return;
+    const int32_t s = scan[e] - 1;
+    const uint64_t k = keys[e];
+    rowidx[s] = (int32_t)(k / (uint64_t)n_cols);
+    colidx[s] = (int32_t)(k % (uint64_t)n_cols);
+    if (slot_ptr) slot_ptr[s] = e;
+}
+
+__global__ void k_sum_slots(const float *__restrict__ e_vals, const int64_t *__restrict__ slot_ptr, int64_t nslots,
+                            float *__restrict__ out) {
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    float acc = 0.f;
+    for (int64_t e = slot_ptr[s]; e < slot_ptr[s + 1]; ++e) acc += e_vals[e];  // input order
+    out[s] = acc;
+}
+
+// ptr[r] = first position p with sorted_rows[p] >= r  (r in [0, n_rows]); sorted_rows int32 ascending
+__global__ void k_lower_bound_rows(const int32_t *__restrict__ sorted_rows, int64_t nnz, int64_t n_rows,
+                                   int64_t *__restrict__ ptr) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rows) return;
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sorted_rows[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    ptr[r] = lo;
+}
+
+__global__ void k_rows_from_ptr(const int64_t *__restrict__ rowptr, int64_t n_rows, int32_t *__restrict__ rowidx) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    for (int64_t e = rowptr[r]; e < rowptr[r + 1]; ++e) rowidx[e] = (int32_t)r;
+}
+
+__global__ void k_check_csr(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx, int64_t n_rows,
+                            int64_t n_cols, int64_t nnz, int *__restrict__ bad) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t b = rowptr[r], e = rowptr[r + 1];
+    if (b > e || b < 0 || e > nnz || (r == 0 && b != 0) || (r == n_rows - 1 && e != nnz)) { atomicExch(bad, 1); return; }
+    for (int64_t k = b; k < e; ++k) {
+        int32_t c = colidx[k];
+        if (c < 0 || c >= n_cols || (k > b && colidx[k - 1] >= c)) { atomicExch(bad, 1); return; }
+    }
+}
+
+__global__ void k_flag_long(const int64_t *__restrict__ rowptr, int64_t n_rows, int32_t *__restrict__ flag,
+                            int64_t *__restrict__ cnt) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t d = rowptr[r + 1] - rowptr[r];
+    bool lg = d > LONG_ROW;
+    flag[r] = lg ? 1 : 0;
+    cnt[r] = lg ? (d + LONG_CHUNK - 1) / LONG_CHUNK : 0;
+}
+
+__global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, const int32_t *__restrict__ pos,
+                            const int64_t *__restrict__ cpos, int32_t *__restrict__ long_rows,
+                            int64_t *__restrict__ long_chunk_ptr, int32_t *__restrict__ chunk_long) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t d = rowptr[r + 1] - rowptr[r];
+    if (d <= LONG_ROW) return;
+    const int32_t p = pos[r];
+    const int64_t c0 = cpos[r];
+    const int64_t nc = (d + LONG_CHUNK - 1) / LONG_CHUNK;
+    long_rows[p] = (int32_t)r;
+    long_chunk_ptr[p] = c0;
+    for (int64_t c = 0; c < nc; ++c) chunk_long[c0 + c] = p;
+}
+
+__global__ void k_make_tkeys(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ colidx, int64_t nnz,
+                             int64_t n_rows, uint64_t *__restrict__ keys, int32_t *__restrict__ payload) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    keys[k] = (uint64_t)colidx[k] * (uint64_t)n_rows + (uint64_t)rowidx[k];
+    payload[k] = (int32_t)k;
+}
+
+__global__ void k_split_tkeys(const uint64_t *__restrict__ keys, int64_t nnz, int64_t n_rows,
+                              int32_t *__restrict__ t_row /* = column of A */, int32_t *__restrict__ t_col /* = row of A */) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    t_row[k] = (int32_t)(keys[k] / (uint64_t)n_rows);
+    t_col[k] = (int32_t)(keys[k] % (uint64_t)n_rows);
+}
+
+// ---- helpers -------------------------------------------------------------------------------
+void free_csr(Csr &m) {
+    if (m.rowptr) (void)hipFree(m.rowptr);
+    if (m.colidx) (void)hipFree(m.colidx);
+    if (m.long_rows) (void)hipFree(m.long_rows);
+    if (m.long_chunk_ptr) (void)hipFree(m.long_chunk_ptr);
+    if (m.chunk_long) (void)hipFree(m.chunk_long);
+    m = Csr();
+}
+
+int build_long_plan(Csr &m, hipStream_t s) {
+    m.n_long = 0; m.n_chunks = 0;
+    if (m.n_rows == 0 || m.nnz == 0) return GNX_OK;
+    DevBuf flag, cnt, pos, cpos, tmp;
+    GNX_HIP(flag.alloc(m.n_rows * sizeof(int32_t)));
+    GNX_HIP(cnt.alloc(m.n_rows * sizeof(int64_t)));
+    GNX_HIP(pos.alloc(m.n_rows * sizeof(int32_t)));
+    GNX_HIP(cpos.alloc(m.n_rows * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_flag_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, flag.as<int32_t>(),
+                       cnt.as<int64_t>());
+    size_t t1 = 0, t2 = 0;
+    GNX_HIP(rocprim::exclusive_scan(nullptr, t1, flag.as<int32_t>(), pos.as<int32_t>(), (int32_t)0, (size_t)m.n_rows,
+                                    rocprim::plus<int32_t>(), s));
+    GNX_HIP(rocprim::exclusive_scan(nullptr, t2, cnt.as<int64_t>(), cpos.as<int64_t>(), (int64_t)0, (size_t)m.n_rows,
+                                    rocprim::plus<int64_t>(), s));
+    GNX_HIP(tmp.alloc(t1 > t2 ? t1 : t2));
+    GNX_HIP(rocprim::exclusive_scan(tmp.p, t1, flag.as<int32_t>(), pos.as<int32_t>(), (int32_t)0, (size_t)m.n_rows,
+                                    rocprim::plus<int32_t>(), s));
+    GNX_HIP(rocprim::exclusive_scan(tmp.p, t2, cnt.as<int64_t>(), cpos.as<int64_t>(), (int64_t)0, (size_t)m.n_rows,
+                                    rocprim::plus<int64_t>(), s));
+    int32_t last_flag = 0, last_pos = 0;
+    int64_t last_cnt = 0, last_cpos = 0;
+    GNX_HIP(hipMemcpyAsync(&last_flag, flag.as<int32_t>() + m.n_rows - 1, 4, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipMemcpyAsync(&last_pos, pos.as<int32_t>() + m.n_rows - 1, 4, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipMemcpyAsync(&last_cnt, cnt.as<int64_t>() + m.n_rows - 1, 8, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipMemcpyAsync(&last_cpos, cpos.as<int64_t>() + m.n_rows - 1, 8, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    m.n_long = (int64_t)last_flag + last_pos;
+    m.n_chunks = last_cnt + last_cpos;
+    if (m.n_long == 0) return GNX_OK;
+    GNX_HIP(hipMalloc((void **)&m.long_rows, m.n_long * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&m.long_chunk_ptr, (m.n_long + 1) * sizeof(int64_t)));
+    GNX_HIP(hipMalloc((void **)&m.chunk_long, m.n_chunks * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_fill_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, pos.as<int32_t>(),
+                       cpos.as<int64_t>(), m.long_rows, m.long_chunk_ptr, m.chunk_long);
+    GNX_HIP(hipMemcpyAsync(m.long_chunk_ptr + m.n_long, &m.n_chunks, 8, hipMemcpyHostToDevice, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    return GNX_OK;
+}
+
+int ensure_partial(gnx_graph *g, size_t bytes) {
+    if (bytes <= g->partial_bytes) return GNX_OK;
+    if (g->partial) (void)hipFree(g->partial);
+    g->partial = nullptr; g->partial_bytes = 0;
+    GNX_HIP(hipMalloc((void **)&g->partial, bytes));
+    g->partial_bytes = bytes;
+    return GNX_OK;
+}
+
+int ensure_transpose(gnx_graph *g, hipStream_t s) {
+    if (g->has_t) return GNX_OK;
+    const Csr &a = g->a;
+    Csr &t = g->t;
+    t.n_rows = a.n_cols; t.n_cols = a.n_rows; t.nnz = a.nnz;
+    GNX_HIP(hipMalloc((void **)&t.rowptr, (t.n_rows + 1) * sizeof(int64_t)));
+    GNX_HIP(hipMalloc((void **)&t.colidx, (t.nnz ? t.nnz : 1) * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&g->t_perm, (t.nnz ? t.nnz : 1) * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&g->t_vals, (t.nnz ? t.nnz : 1) * sizeof(float)));
+    if (t.nnz == 0) {
+        GNX_HIP(hipMemsetAsync(t.rowptr, 0, (t.n_rows + 1) * sizeof(int64_t), s));
+        GNX_HIP(hipStreamSynchronize(s));
+        g->has_t = true;
+        return GNX_OK;
+    }
+    DevBuf k0, k1, p0, trow, tmp;
+    GNX_HIP(k0.alloc(t.nnz * 8)); GNX_HIP(k1.alloc(t.nnz * 8));
+    GNX_HIP(p0.alloc(t.nnz * 4)); GNX_HIP(trow.alloc(t.nnz * 4));
+    hipLaunchKernelGGL(k_make_tkeys, dim3(blocks_for(t.nnz)), dim3(256), 0, s, g->rowidx, a.colidx, a.nnz, a.n_rows,
+                       k0.as<uint64_t>(), p0.as<int32_t>());
+    const unsigned end_bit = bits_for((uint64_t)a.n_rows * (uint64_t)a.n_cols);
+    size_t tb = 0;
+    GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<int32_t>(), g->t_perm,
+                                      (size_t)t.nnz, 0u, end_bit, s));
+    GNX_HIP(tmp.alloc(tb));
+    GNX_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<int32_t>(), g->t_perm,
+                                      (size_t)t.nnz, 0u, end_bit, s));
+    hipLaunchKernelGGL(k_split_tkeys, dim3(blocks_for(t.nnz)), dim3(256), 0, s, k1.as<uint64_t>(), t.nnz, a.n_rows,
+                       trow.as<int32_t>(), t.colidx);
+    hipLaunchKernelGGL(k_lower_bound_rows, dim3(blocks_for(t.n_rows + 1)), dim3(256), 0, s, trow.as<int32_t>(), t.nnz,
+                       t.n_rows, t.rowptr);
+    GNX_HIP(hipStreamSynchronize(s));
+    int rc = build_long_plan(t, s);
+    if (rc != GNX_OK) return rc;
+    g->has_t = true;
+    return GNX_OK;
+}
+
+static int finish_graph(gnx_graph *g, hipStream_t s) {
+    int rc = build_long_plan(g->a, s);
+    if (rc != GNX_OK) return rc;
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+}  // namespace gnx
+
+using namespace gnx;
+
+extern "C" {
+
+const char *gnx_last_error(void) { return g_err; }
+int gnx_version(void) { return GNX_VERSION_NUM; }
+
+int gnx_graph_destroy(gnx_graph_t g) {
+    if (!g) return GNX_OK;
+    free_csr(g->a);
+    free_csr(g->t);
+    if (g->raw_vals) (void)hipFree(g->raw_vals);
+    if (g->rowidx) (void)hipFree(g->rowidx);
+    if (g->e_vals) (void)hipFree(g->e_vals);
+    if (g->slot_ptr) (void)hipFree(g->slot_ptr);
+    if (g->t_perm) (void)hipFree(g->t_perm);
+    if (g->t_vals) (void)hipFree(g->t_vals);
+    if (g->partial) (void)hipFree(g->partial);
+    if (g->deg) (void)hipFree(g->deg);
+    delete g;
+    return GNX_OK;
+}
+
+int gnx_graph_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_indices, const float *d_values,
+                         void *stream, gnx_graph_t *out) {
+    GNX_CHECK_ARG(out != nullptr, "gnx_graph_create_coo: out is NULL");
+    *out = nullptr;
+    GNX_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "gnx_graph_create_coo: negative size");
+    GNX_CHECK_ARG(n_rows < INT32_MAX && n_cols < INT32_MAX, "gnx_graph_create_coo: more than 2^31-1 rows/cols per handle");
+    GNX_CHECK_ARG(nnz < INT32_MAX, "gnx_graph_create_coo: more than 2^31-1 entries per handle");
+    GNX_CHECK_ARG(nnz == 0 || (d_indices && d_values), "gnx_graph_create_coo: NULL indices/values");
+    hipStream_t s = (hipStream_t)stream;
+    gnx_graph *g = new gnx_graph();
+    struct Guard { gnx_graph *g; ~Guard() { if (g) gnx_graph_destroy(g); } } guard{g};
+    Csr &a = g->a;
+    a.n_rows = n_rows; a.n_cols = n_cols;
+    g->nnz_entries = nnz;
+    GNX_HIP(hipMalloc((void **)&a.rowptr, (n_rows + 1) * sizeof(int64_t)));
+    if (nnz == 0) {
+        a.nnz = 0;
+        GNX_HIP(hipMemsetAsync(a.rowptr, 0, (n_rows + 1) * sizeof(int64_t), s));
+        GNX_HIP(hipMalloc((void **)&a.colidx, 16));
+        GNX_HIP(hipMalloc((void **)&g->raw_vals, 16));
+        GNX_HIP(hipMalloc((void **)&g->rowidx, 16));
+        GNX_HIP(hipStreamSynchronize(s));
+        guard.g = nullptr; *out = g;
+        return GNX_OK;
+    }
+    DevBuf k0, k1, v1, head, scan, tmp, bad;
+    GNX_HIP(k0.alloc(nnz * 8)); GNX_HIP(k1.alloc(nnz * 8));
+    GNX_HIP(v1.alloc(nnz * 4));
+    GNX_HIP(bad.alloc(4));
+    GNX_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    hipLaunchKernelGGL(k_make_keys, dim3(blocks_for(nnz)), dim3(256), 0, s, d_indices, nnz, n_rows, n_cols,
+                       k0.as<uint64_t>(), bad.as<int>());
+    const unsigned end_bit = bits_for((uint64_t)n_rows * (uint64_t)n_cols);
+    size_t tb = 0;
+    GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), d_values, v1.as<float>(),
+                                      (size_t)nnz, 0u, end_bit, s));
+    GNX_HIP(tmp.alloc(tb));
+    GNX_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), d_values, v1.as<float>(),
+                                      (size_t)nnz, 0u, end_bit, s));
+    // k0 is free again: reuse as head flags + scan (2 x int32 per entry fits in 8 bytes/entry)
+    int32_t *d_head = k0.as<int32_t>();
+    int32_t *d_scan = d_head + nnz;
+    hipLaunchKernelGGL(k_heads, dim3(blocks_for(nnz)), dim3(256), 0, s, k1.as<uint64_t>(), nnz, d_head);
+    size_t sb = 0;
+    GNX_HIP(rocprim::inclusive_scan(nullptr, sb, d_head, d_scan, (size_t)nnz, rocprim::plus<int32_t>(), s));
+    if (sb > tb) { (void)hipFree(tmp.release()); GNX_HIP(tmp.alloc(sb)); }
+    GNX_HIP(rocprim::inclusive_scan(tmp.p, sb, d_head, d_scan, (size_t)nnz, rocprim::plus<int32_t>(), s));
+    int h_bad = 0; int32_t h_nslots = 0;
+    GNX_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipMemcpyAsync(&h_nslots, d_scan + nnz - 1, 4, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    GNX_CHECK_ARG(h_bad == 0, "gnx_graph_create_coo: an index lies outside the %lld x %lld shape", (long long)n_rows,
+                  (long long)n_cols);
+    a.nnz = h_nslots;
+    g->has_dups = (a.nnz != nnz);
+    GNX_HIP(hipMalloc((void **)&a.colidx, a.nnz * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&g->rowidx, a.nnz * sizeof(int32_t)));
+    if (g->has_dups) GNX_HIP(hipMalloc((void **)&g->slot_ptr, (a.nnz + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(k_fill_slots, dim3(blocks_for(nnz)), dim3(256), 0, s, k1.as<uint64_t>(), d_scan, nnz, n_cols,
+                       a.colidx, g->rowidx, g->slot_ptr);
+    if (g->has_dups) {
+        GNX_HIP(hipMemcpyAsync(g->slot_ptr + a.nnz, &nnz, 8, hipMemcpyHostToDevice, s));
+        g->e_vals = (float *)v1.release();
+        GNX_HIP(hipMalloc((void **)&g->raw_vals, a.nnz * sizeof(float)));
+        hipLaunchKernelGGL(k_sum_slots, dim3(blocks_for(a.nnz)), dim3(256), 0, s, g->e_vals, g->slot_ptr, a.nnz,
+                           g->raw_vals);
+    } else {
+        g->raw_vals = (float *)v1.release();
+    }
+    hipLaunchKernelGGL(k_lower_bound_rows, dim3(blocks_for(n_rows + 1)), dim3(256), 0, s, g->rowidx, a.nnz, n_rows,
+                       a.rowptr);
+    GNX_HIP(hipStreamSynchronize(s));
+    int rc = finish_graph(g, s);
+    if (rc != GNX_OK) return rc;
+    guard.g = nullptr; *out = g;
+    return GNX_OK;
+}
+
+int gnx_graph_create_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr, const int32_t *d_colidx,
+                         const float *d_values, void *stream, gnx_graph_t *out) {
+    GNX_CHECK_ARG(out != nullptr, "gnx_graph_create_csr: out is NULL");
+    *out = nullptr;
+    GNX_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "gnx_graph_create_csr: negative size");
+    GNX_CHECK_ARG(n_rows < INT32_MAX && n_cols < INT32_MAX && nnz < INT32_MAX, "gnx_graph_create_csr: size over 2^31-1");
+    GNX_CHECK_ARG(d_rowptr && (nnz == 0 || (d_colidx && d_values)), "gnx_graph_create_csr: NULL array");
+    hipStream_t s = (hipStream_t)stream;
+    gnx_graph *g = new gnx_graph();
+    struct Guard { gnx_graph *g; ~Guard() { if (g) gnx_graph_destroy(g); } } guard{g};
+    Csr &a = g->a;
+    a.n_rows = n_rows; a.n_cols = n_cols; a.nnz = nnz; g->nnz_entries = nnz;
+    const size_t nz = nnz ? nnz : 4;
+    GNX_HIP(hipMalloc((void **)&a.rowptr, (n_rows + 1) * sizeof(int64_t)));
+    GNX_HIP(hipMalloc((void **)&a.colidx, nz * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&g->raw_vals, nz * sizeof(float)));
+    GNX_HIP(hipMalloc((void **)&g->rowidx, nz * sizeof(int32_t)));
+    GNX_HIP(hipMemcpyAsync(a.rowptr, d_rowptr, (n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    if (nnz) {
+        GNX_HIP(hipMemcpyAsync(a.colidx, d_colidx, nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        GNX_HIP(hipMemcpyAsync(g->raw_vals, d_values, nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    DevBuf bad;
+    GNX_HIP(bad.alloc(4));
+    GNX_HIP(hipMemsetAsync(bad.p, 0, 4, s));
+    if (n_rows) {
+        hipLaunchKernelGGL(k_check_csr, dim3(blocks_for(n_rows)), dim3(256), 0, s, a.rowptr, a.colidx, n_rows, n_cols,
+                           nnz, bad.as<int>());
+        hipLaunchKernelGGL(k_rows_from_ptr, dim3(blocks_for(n_rows)), dim3(256), 0, s, a.rowptr, n_rows, g->rowidx);
+    }
+    int h_bad = 0;
+    GNX_HIP(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    GNX_CHECK_ARG(h_bad == 0, "gnx_graph_create_csr: rowptr/colidx are not a valid sorted CSR for this shape");
+    int rc = finish_graph(g, s);
+    if (rc != GNX_OK) return rc;
+    guard.g = nullptr; *out = g;
+    return GNX_OK;
+}
+
+int gnx_graph_info(gnx_graph_t g, int64_t *n_rows, int64_t *n_cols, int64_t *nnz_entries, int64_t *nnz_coalesced) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_info: NULL handle");
+    if (n_rows) *n_rows = g->a.n_rows;
+    if (n_cols) *n_cols = g->a.n_cols;
+    if (nnz_entries) *nnz_entries = g->nnz_entries;
+    if (nnz_coalesced) *nnz_coalesced = g->a.nnz;
+    return GNX_OK;
+}
+
+int gnx_graph_csr(gnx_graph_t g, const int64_t **d_rowptr, const int32_t **d_colidx, const float **d_raw_values) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_csr: NULL handle");
+    if (d_rowptr) *d_rowptr = g->a.rowptr;
+    if (d_colidx) *d_colidx = g->a.colidx;
+    if (d_raw_values) *d_raw_values = g->raw_vals;
+    return GNX_OK;
+}
+
+int gnx_graph_export(gnx_graph_t g, int64_t *d_rowptr_out, int32_t *d_colidx_out, float *d_raw_values_out,
+                     int32_t *d_rowidx_out, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_export: NULL handle");
+    hipStream_t s = (hipStream_t)stream;
+    const Csr &a = g->a;
+    if (d_rowptr_out) GNX_HIP(hipMemcpyAsync(d_rowptr_out, a.rowptr, (a.n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    if (a.nnz > 0) {
+        if (d_colidx_out) GNX_HIP(hipMemcpyAsync(d_colidx_out, a.colidx, a.nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (d_raw_values_out) GNX_HIP(hipMemcpyAsync(d_raw_values_out, g->raw_vals, a.nnz * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (d_rowidx_out) GNX_HIP(hipMemcpyAsync(d_rowidx_out, g->rowidx, a.nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    }
+    return GNX_OK;
+}
+
+const char *gnx_graph_last_kernel(gnx_graph_t g) { return g ? g->last_kernel : ""; }
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// Internal declarations shared by the libgnx.so translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/gnx.h"
+
+#define GNX_VERSION_NUM 100 /* 0.1.0 */
+
+namespace gnx {
+
+void set_error(const char *fmt, ...);
+
+#define GNX_HIP(expr)                                                                   \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            gnx::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GNX_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define GNX_CHECK_ARG(cond, ...)                                                        \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            gnx::set_error(__VA_ARGS__);                                                \
+            return GNX_ERR_INVALID;                                                     \
+        }                                                                               \
+    } while (0)
+
+// Rows whose entry count exceeds LONG_ROW are cut into chunks of LONG_CHUNK entries that
+// separate waves sum into a partial slab; a second kernel adds a row's partials in chunk
+// order (fixed order => bitwise reproducible) and applies the epilogue.
+constexpr int LONG_ROW = 512;
+constexpr int LONG_CHUNK = 512;
+
+// One CSR-like structure (the matrix itself, or its transpose).
+struct Csr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t *rowptr = nullptr;  // [n_rows+1]
+    int32_t *colidx = nullptr;  // [nnz]
+    // long-row split plan
+    int64_t n_long = 0, n_chunks = 0;
+    int32_t *long_rows = nullptr;       // [n_long] row ids
+    int64_t *long_chunk_ptr = nullptr;  // [n_long+1] first chunk of each long row
+    int32_t *chunk_long = nullptr;      // [n_chunks] index into long_rows
+};
+
+}  // namespace gnx
+
+struct gnx_graph {
+    gnx::Csr a;            // coalesced matrix
+    float *raw_vals = nullptr;   // [a.nnz] summed duplicate values
+    int32_t *rowidx = nullptr;   // [a.nnz] row of every coalesced entry
+    // un-coalesced entries (only when duplicates exist; otherwise entries == coalesced)
+    int64_t nnz_entries = 0;
+    bool has_dups = false;
+    float *e_vals = nullptr;     // [nnz_entries] entry values, sorted by (row, col), input order among dups
+    int64_t *slot_ptr = nullptr; // [a.nnz+1] entry range of every coalesced slot
+    // transposed structure (lazy)
+    bool has_t = false;
+    gnx::Csr t;                  // t.n_rows = a.n_cols
+    int32_t *t_perm = nullptr;   // [a.nnz] coalesced slot of every transposed entry
+    float *t_vals = nullptr;     // [a.nnz] scratch: values gathered into transposed order
+    // partial slab for long rows (grown on demand)
+    float *partial = nullptr;
+    size_t partial_bytes = 0;
+    float *deg = nullptr;        // [a.n_cols] scratch for column sums / degree scales (lazy)
+    const char *last_kernel = "";
+};
+
+namespace gnx {
+
+int build_long_plan(Csr &m, hipStream_t s);
+void free_csr(Csr &m);
+int ensure_transpose(gnx_graph *g, hipStream_t s);
+int ensure_partial(gnx_graph *g, size_t bytes);
+
+struct SpmmArgs {
+    const int64_t *rowptr;
+    const int32_t *colidx;
+    const float *vals;
+    const float *diag;
+    const float *X;
+    int64_t ldx;
+    const float *H0;
+    int64_t ldh0;
+    float beta, alpha;
+    int act;
+    float *out;
+    int64_t ldo;
+    int64_t n_rows;
+    int C;
+    // long rows
+    const int32_t *long_rows;
+    const int64_t *long_chunk_ptr;
+    const int32_t *chunk_long;
+    float *partial;
+    int64_t n_long, n_chunks;
+};
+
+int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);
+
+}  // namespace gnx

@@ -1,0 +1,228 @@
+// Normalisation of the adjacency on gfx950: GNN.get_adjacency of the reference
+// (gnntf/core/gnn/gnn.py:36-50) and the edge dropout in front of it
+// (gnntf/core/nn/layered.py:47-50).  All of this is HBM-bound integer/float streaming over
+// nnz-sized arrays; no LDS tiling is needed, only coalesced slot-parallel passes.
+#include "gnx_internal.h"
+
+using namespace gnx;
+
+namespace {
+
+inline unsigned blocks_for(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// ---- counter RNG: the same integer arithmetic as oracle/gnntf_oracle.py:hash_u24 ----------
+__device__ __forceinline__ uint64_t fin(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint32_t hash_u24(uint64_t seed, uint64_t stream, uint64_t row, uint64_t col, uint64_t dup) {
+    const uint64_t k = seed ^ (stream * 0xD1342543DE82EF95ull);
+    uint64_t x = fin(k + row * 0x9E3779B97F4A7C15ull);
+    x ^= col * 0xC2B2AE3D27D4EB4Full;
+    x = fin(x + dup * 0x165667B19E3779F9ull);
+    return (uint32_t)(x >> 40);
+}
+
+struct Drop {
+    uint64_t seed, stream;
+    uint32_t thr;    // keep iff hash >= thr
+    float scale;     // 1/(1-p)
+    const float *e_vals;       // entry values (null when no duplicates)
+    const int64_t *slot_ptr;   // entry range per slot (null when no duplicates)
+};
+
+// value of coalesced slot k after per-entry dropout (layered.py:50: kept * 1/(1-p), dropped -> 0)
+template <bool DROPOUT>
+__device__ __forceinline__ float slot_value(const float *__restrict__ raw, const Drop &d, int64_t k, int32_t row, int32_t col) {
+    if (!DROPOUT) return raw[k];
+    if (d.slot_ptr == nullptr)
+        return hash_u24(d.seed, d.stream, (uint64_t)row, (uint64_t)col, 0) >= d.thr ? raw[k] * d.scale : 0.f;
+    float acc = 0.f;
+    const int64_t b = d.slot_ptr[k], e = d.slot_ptr[k + 1];
+    for (int64_t i = b; i < e; ++i)
+        if (hash_u24(d.seed, d.stream, (uint64_t)row, (uint64_t)col, (uint64_t)(i - b)) >= d.thr) acc += d.e_vals[i] * d.scale;
+    return acc;
+}
+
+// column sums over the transposed structure: 8 lanes per column, fixed reduction tree.
+template <bool DROPOUT>
+__global__ void k_colsum_short(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
+                               const int32_t *__restrict__ t_perm, const float *__restrict__ raw, Drop d, int64_t n_cols,
+                               float *__restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = gid >> 3;
+    const int sub = (int)(gid & 7);
+    float acc = 0.f;
+    bool is_long = false;
+    if (j < n_cols) {
+        const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
+        is_long = (e - b) > LONG_ROW;
+        if (!is_long)
+            for (int64_t p = b + sub; p < e; p += 8) acc += slot_value<DROPOUT>(raw, d, t_perm[p], t_colidx[p], (int32_t)j);
+    }
+    acc += __shfl_xor(acc, 4);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 1);
+    if (j < n_cols && sub == 0 && !is_long) out[j] = acc;
+}
+
+// one 256-thread block per long column; strided partial sums, then a fixed LDS tree.
+template <bool DROPOUT>
+__global__ __launch_bounds__(256) void k_colsum_long(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
+                                                     const int32_t *__restrict__ t_perm, const float *__restrict__ raw, Drop d,
+                                                     const int32_t *__restrict__ long_rows, float *__restrict__ out) {
+    __shared__ float red[256];
+    const int32_t j = long_rows[blockIdx.x];
+    const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
+    float acc = 0.f;
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) acc += slot_value<DROPOUT>(raw, d, t_perm[p], t_colidx[p], j);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = red[0];
+}
+
+// gnn.py:41 / :44 with optional "+I before" folded in as +1 on every column sum
+__global__ void k_degree_scale(float *__restrict__ d, int64_t n, int normalized, float eye) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float x = d[j] + eye;
+    if (normalized == GNX_NORM_SYMMETRIC) x = sqrtf(x);
+    d[j] = (x != 0.f) ? 1.0f / x : 0.f;   // tf.math.divide_no_nan(1., x)
+}
+
+// gnn.py:42 / :45: v_ij <- (rs[i] * v_ij) * cs[j]
+template <bool DROPOUT>
+__global__ void k_scale_values(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ colidx,
+                               const float *__restrict__ raw, Drop d, const float *__restrict__ rs,
+                               const float *__restrict__ cs, int64_t nnz, float *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int32_t r = rowidx[k], c = colidx[k];
+    float v = slot_value<DROPOUT>(raw, d, k, r, c);
+    if (rs) v = rs[r] * v;
+    if (cs) v = v * cs[c];
+    out[k] = v;
+}
+
+// diagonal weight of the identity added by add_eye (gnn.py:39,49)
+__global__ void k_diag(const float *__restrict__ deg, int64_t n, int mode /*0: ones, 1: deg^2, 2: deg*/, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = mode == 0 ? 1.0f : (mode == 1 ? deg[i] * 1.0f * deg[i] : deg[i]);
+}
+
+int make_drop(gnx_graph *g, float p, uint64_t seed, uint64_t stream_id, Drop &d) {
+    GNX_CHECK_ARG(p >= 0.f && p < 1.f, "dropout rate %g outside [0, 1)", (double)p);
+    d.seed = seed; d.stream = stream_id;
+    d.thr = (uint32_t)((double)p * 16777216.0);
+    d.scale = 1.0f / (1.0f - p);
+    d.e_vals = g->has_dups ? g->e_vals : nullptr;
+    d.slot_ptr = g->has_dups ? g->slot_ptr : nullptr;
+    return GNX_OK;
+}
+
+int ensure_deg(gnx_graph *g) {
+    if (g->deg) return GNX_OK;
+    GNX_HIP(hipMalloc((void **)&g->deg, (g->a.n_cols ? g->a.n_cols : 1) * sizeof(float)));
+    return GNX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id, float *d_colsum_out, void *stream) {
+    GNX_CHECK_ARG(g != nullptr && d_colsum_out != nullptr, "gnx_graph_colsum: NULL argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    Drop d;
+    rc = make_drop(g, dropout_p, seed, stream_id, d);
+    if (rc != GNX_OK) return rc;
+    const Csr &t = g->t;
+    if (t.n_rows == 0) return GNX_OK;
+    const bool drop = dropout_p > 0.f;
+    const unsigned nb = blocks_for(t.n_rows * 8);
+    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.n_rows, d_colsum_out);
+    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.n_rows, d_colsum_out);
+    if (t.n_long > 0) {
+        if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.long_rows, d_colsum_out);
+        else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.long_rows, d_colsum_out);
+    }
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_degree_scale(float *d_deg, int64_t n, int normalized, int add_eye_before, void *stream) {
+    GNX_CHECK_ARG(n >= 0 && (n == 0 || d_deg != nullptr), "gnx_degree_scale: NULL array");
+    GNX_CHECK_ARG(normalized == GNX_NORM_SYMMETRIC || normalized == GNX_NORM_BIPARTITE,
+                  "Invalid matrix normalization");
+    if (n == 0) return GNX_OK;
+    hipLaunchKernelGGL(k_degree_scale, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, d_deg, n, normalized,
+                       add_eye_before ? 1.0f : 0.0f);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_graph_scale_values(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id, const float *d_row_scale,
+                           const float *d_col_scale, float *d_vals_out, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_scale_values: NULL handle");
+    GNX_CHECK_ARG(g->a.nnz == 0 || d_vals_out != nullptr, "gnx_graph_scale_values: NULL output");
+    Drop d;
+    int rc = make_drop(g, dropout_p, seed, stream_id, d);
+    if (rc != GNX_OK) return rc;
+    if (g->a.nnz == 0) return GNX_OK;
+    const unsigned nb = blocks_for(g->a.nnz);
+    hipStream_t s = (hipStream_t)stream;
+    if (dropout_p > 0.f) hipLaunchKernelGGL(k_scale_values<true>, dim3(nb), dim3(256), 0, s, g->rowidx, g->a.colidx, g->raw_vals, d, d_row_scale, d_col_scale, g->a.nnz, d_vals_out);
+    else                 hipLaunchKernelGGL(k_scale_values<false>, dim3(nb), dim3(256), 0, s, g->rowidx, g->a.colidx, g->raw_vals, d, d_row_scale, d_col_scale, g->a.nnz, d_vals_out);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed, uint64_t stream_id,
+                        float *d_vals_out, float *d_diag_out, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_normalize: NULL handle");
+    GNX_CHECK_ARG(normalized == GNX_NORM_NONE || normalized == GNX_NORM_SYMMETRIC || normalized == GNX_NORM_BIPARTITE,
+                  "Invalid matrix normalization");
+    GNX_CHECK_ARG(add_eye == GNX_EYE_NONE || add_eye == GNX_EYE_BEFORE || add_eye == GNX_EYE_AFTER,
+                  "gnx_graph_normalize: invalid add_eye %d", add_eye);
+    GNX_CHECK_ARG(add_eye == GNX_EYE_NONE || d_diag_out != nullptr, "gnx_graph_normalize: add_eye needs d_diag_out");
+    GNX_CHECK_ARG((normalized == GNX_NORM_NONE && add_eye == GNX_EYE_NONE) || g->a.n_rows == g->a.n_cols,
+                  "gnx_graph_normalize: normalisation / add_eye need a square graph (%lld x %lld)",
+                  (long long)g->a.n_rows, (long long)g->a.n_cols);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = g->a.n_rows;
+    int rc;
+    if (normalized == GNX_NORM_NONE) {
+        rc = gnx_graph_scale_values(g, dropout_p, seed, stream_id, nullptr, nullptr, d_vals_out, stream);
+        if (rc != GNX_OK) return rc;
+        if (add_eye != GNX_EYE_NONE && n > 0)
+            hipLaunchKernelGGL(k_diag, dim3(blocks_for(n)), dim3(256), 0, s, (const float *)nullptr, n, 0, d_diag_out);
+        GNX_HIP(hipGetLastError());
+        return GNX_OK;
+    }
+    rc = ensure_deg(g);
+    if (rc != GNX_OK) return rc;
+    rc = gnx_graph_colsum(g, dropout_p, seed, stream_id, g->deg, stream);
+    if (rc != GNX_OK) return rc;
+    rc = gnx_degree_scale(g->deg, g->a.n_cols, normalized, add_eye == GNX_EYE_BEFORE, stream);
+    if (rc != GNX_OK) return rc;
+    rc = gnx_graph_scale_values(g, dropout_p, seed, stream_id, g->deg, normalized == GNX_NORM_SYMMETRIC ? g->deg : nullptr,
+                                d_vals_out, stream);
+    if (rc != GNX_OK) return rc;
+    if (add_eye != GNX_EYE_NONE && n > 0) {
+        const int mode = add_eye == GNX_EYE_AFTER ? 0 : (normalized == GNX_NORM_SYMMETRIC ? 1 : 2);
+        hipLaunchKernelGGL(k_diag, dim3(blocks_for(n)), dim3(256), 0, s, g->deg, n, mode, d_diag_out);
+    }
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,406 @@
+// The hot path on gfx950: CSR SpMM with the residual mix fused into its epilogue.
+//
+//   out[i,:] = act( beta * ( sum_j A[i,j] X[j,:] + diag[i] X[i,:] ) + alpha * H0[i,:] )
+//
+// replaces tf.sparse.sparse_dense_matmul + the three element-wise ops behind it in the
+// reference (gnntf/core/gnn/architectures/filter.py:19-22; gcn.py:88).
+//
+// The kernel is HBM-bound (2 flop per 4 gathered bytes), so the design is about memory
+// parallelism, not MFMA:
+//   * wide features (C >= 129 or any C the sub-wave path cannot hold): one 64-lane wave per
+//     row, each lane owning VEC contiguous columns, so every neighbour row is ONE coalesced
+//     wave-instruction (C = 256: 64 x float4 = the whole 1 KiB row).  The row's (col, val)
+//     pairs are fetched 64 at a time with one coalesced load and broadcast from registers
+//     with v_readlane, so the gather address is wave-uniform (SGPR base + lane offset), and
+//     U neighbour rows are kept in flight per wave before the first FMA;
+//   * narrow features: G = 4..32 lanes per row, 64/G rows per wave;
+//   * power-law rows: a row with more than LONG_ROW entries is cut into LONG_CHUNK-entry
+//     chunks summed by separate waves into a partial slab, then added in chunk order by a
+//     second kernel (fixed order: results are bitwise reproducible, no float atomics).
+#include "gnx_internal.h"
+
+using namespace gnx;
+
+namespace {
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int VEC>
+__device__ __forceinline__ void vload(float (&x)[VEC], const float *__restrict__ p) {
+    using T = typename VecT<VEC>::type;
+    const T v = *reinterpret_cast<const T *>(p);
+    __builtin_memcpy(x, &v, sizeof(T));
+}
+template <int VEC>
+__device__ __forceinline__ void vstore(float *__restrict__ p, const float (&x)[VEC]) {
+    using T = typename VecT<VEC>::type;
+    T v;
+    __builtin_memcpy(&v, x, sizeof(T));
+    *reinterpret_cast<T *>(p) = v;
+}
+
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Sum of w_e * X[col_e, c .. c+VEC) over entries [beg, end) of one row; the whole wave works
+// on the same entries (beg/end wave-uniform), lane `lane` owns columns c .. c+VEC.
+template <int VEC, int U>
+__device__ __forceinline__ void wave_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                                const float *__restrict__ X, int64_t ldx, int64_t beg, int64_t end,
+                                                int c, int lane, float (&acc)[VEC]) {
+    for (int64_t base = beg; base < end; base += 64) {
+        const int n = (int)((end - base) < 64 ? (end - base) : 64);
+        int mycol = 0;
+        float myval = 0.f;
+        if (lane < n) {
+            mycol = colidx[base + lane];
+            myval = vals[base + lane];
+        }
+        int i = 0;
+        for (; i + U <= n; i += U) {
+            float x[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = readlane_i(mycol, i + u);
+                vload<VEC>(x[u], X + (int64_t)j * ldx + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float w = readlane_f(myval, i + u);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[u][v], acc[v]);
+            }
+        }
+        if (i < n) {  // 1 .. U-1 entries left: issue all loads, then all FMAs (wave-uniform branches)
+            float x[U][VEC];
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                if (i + u < n) {
+                    const int j = readlane_i(mycol, i + u);
+                    vload<VEC>(x[u], X + (int64_t)j * ldx + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                if (i + u < n) {
+                    const float w = readlane_f(myval, i + u);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[u][v], acc[v]);
+                }
+            }
+        }
+    }
+}
+
+// filter.py:20-22: out = act(acc*beta + h0*alpha), with the add_eye diagonal folded in first.
+template <int VEC>
+__device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, int c, bool active, float (&acc)[VEC]) {
+    if (!active) return;
+    if (p.diag) {
+        const float d = p.diag[row];
+        float xr[VEC];
+        vload<VEC>(xr, p.X + row * p.ldx + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(d, xr[v], acc[v]);
+    }
+    float o[VEC];
+    if (p.H0) {
+        float h0[VEC];
+        vload<VEC>(h0, p.H0 + row * p.ldh0 + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = acc[v] * p.beta + h0[v] * p.alpha;
+    } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = acc[v] * p.beta;
+    }
+    if (p.act == GNX_ACT_RELU) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] = fmaxf(o[v], 0.f);
+    }
+    vstore<VEC>(p.out + row * p.ldo + c, o);
+}
+
+// ---- wide path: one wave per row -----------------------------------------------------------
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t row = (int64_t)blockIdx.x * 4 + wib;
+    if (row >= p.n_rows) return;
+    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    if (end - beg > LONG_ROW) return;  // k_spmm_long_* take it
+    for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
+        const int c = c0 + lane * VEC;
+        const bool active = c < p.C;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        wave_accumulate<VEC, U>(p.colidx, p.vals, p.X, p.ldx, beg, end, active ? c : 0, lane, acc);
+        epilogue_store<VEC>(p, row, c, active, acc);
+    }
+}
+
+// ---- narrow path: G lanes per row, 256/G rows per block ---------------------------------------
+template <int VEC, int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+    if (row >= p.n_rows) return;
+    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    if (end - beg > LONG_ROW) return;
+    for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
+        const int c = c0 + sub * VEC;
+        const bool active = c < p.C;
+        const float *__restrict__ Xc = p.X + (active ? c : 0);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        int64_t e = beg;
+        for (; e + U <= end; e += U) {
+            float x[U][VEC];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int j = p.colidx[e + u];
+                w[u] = p.vals[e + u];
+                vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+        }
+        for (; e < end; ++e) {
+            float x[VEC];
+            const int j = p.colidx[e];
+            const float w = p.vals[e];
+            vload<VEC>(x, Xc + (int64_t)j * p.ldx);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[v], acc[v]);
+        }
+        epilogue_store<VEC>(p, row, c, active, acc);
+    }
+}
+
+// ---- long rows ---------------------------------------------------------------------------------
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void k_spmm_long_partial(const SpmmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + wib;
+    if (chunk >= p.n_chunks) return;
+    const int32_t li = p.chunk_long[chunk];
+    const int64_t row = p.long_rows[li];
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t rend = p.rowptr[row + 1];
+    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
+        const int c = c0 + lane * VEC;
+        const bool active = c < p.C;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        wave_accumulate<VEC, U>(p.colidx, p.vals, p.X, p.ldx, beg, end, active ? c : 0, lane, acc);
+        if (active) vstore<VEC>(p.partial + chunk * (int64_t)p.C + c, acc);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t li = (int64_t)blockIdx.x * 4 + wib;
+    if (li >= p.n_long) return;
+    const int64_t row = p.long_rows[li];
+    const int64_t cb = p.long_chunk_ptr[li], ce = p.long_chunk_ptr[li + 1];
+    for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
+        const int c = c0 + lane * VEC;
+        const bool active = c < p.C;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        if (active) {
+            for (int64_t k = cb; k < ce; ++k) {  // chunk order
+                float x[VEC];
+                vload<VEC>(x, p.partial + k * (int64_t)p.C + c);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += x[v];
+            }
+        }
+        epilogue_store<VEC>(p, row, c, active, acc);
+    }
+}
+
+// ---- small helpers --------------------------------------------------------------------------------
+__global__ void k_gather_vals(const float *__restrict__ vals, const int32_t *__restrict__ perm, int64_t n,
+                              float *__restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = vals[perm[k]];
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X, int64_t ldx, const int64_t *__restrict__ idx,
+                                                     int64_t n_idx, int C, float *__restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_idx) return;
+    const int64_t src = idx[r];
+    for (int c = lane * VEC; c < C; c += 64 * VEC) {
+        float x[VEC];
+        vload<VEC>(x, X + src * ldx + c);
+        vstore<VEC>(out + r * ldo + c, x);
+    }
+}
+
+inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+inline bool aligned(const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
+
+// widest vector width every row start allows
+int pick_vec(const SpmmArgs &p) {
+    for (int vec = 4; vec > 1; vec >>= 1) {
+        const size_t a = vec * sizeof(float);
+        if (p.C % vec == 0 && p.ldx % vec == 0 && p.ldo % vec == 0 && (p.H0 == nullptr || p.ldh0 % vec == 0) &&
+            aligned(p.X, a) && aligned(p.out, a) && aligned(p.H0, a))
+            return vec;
+    }
+    return 1;
+}
+
+#define GNX_LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, __VA_ARGS__)
+
+template <int VEC>
+const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
+    const int lanes = (p.C + VEC - 1) / VEC;  // lanes needed to cover one row
+    if (lanes > 32) { GNX_LAUNCH((k_spmm_wave<VEC, 8>), blocks_for(p.n_rows, 4), p); return "spmm_wave"; }
+    if (lanes > 16) { GNX_LAUNCH((k_spmm_group<VEC, 32, 4>), blocks_for(p.n_rows, 8), p); return "spmm_group32"; }
+    if (lanes > 8)  { GNX_LAUNCH((k_spmm_group<VEC, 16, 4>), blocks_for(p.n_rows, 16), p); return "spmm_group16"; }
+    if (lanes > 4)  { GNX_LAUNCH((k_spmm_group<VEC, 8, 4>), blocks_for(p.n_rows, 32), p); return "spmm_group8"; }
+    GNX_LAUNCH((k_spmm_group<VEC, 4, 4>), blocks_for(p.n_rows, 64), p);
+    return "spmm_group4";
+}
+
+template <int VEC>
+void launch_long(const SpmmArgs &p, hipStream_t s) {
+    GNX_LAUNCH((k_spmm_long_partial<VEC, 8>), blocks_for(p.n_chunks, 4), p);
+    GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
+}
+
+int check_common(const char *fn, gnx_graph *g, const float *X, int64_t ldx, int64_t C, const float *H0, int64_t ldh0,
+                 float *out, int64_t ldo) {
+    GNX_CHECK_ARG(g != nullptr, "%s: NULL handle", fn);
+    GNX_CHECK_ARG(C >= 1 && C <= (1 << 20), "%s: feature width %lld not in [1, 2^20]", fn, (long long)C);
+    GNX_CHECK_ARG(X != nullptr && out != nullptr, "%s: NULL X/out", fn);
+    GNX_CHECK_ARG(ldx >= C && ldo >= C && (H0 == nullptr || ldh0 >= C), "%s: leading dimension smaller than C", fn);
+    GNX_CHECK_ARG((const void *)X != (const void *)out, "%s: out must not alias X", fn);
+    return GNX_OK;
+}
+
+}  // namespace
+
+namespace gnx {
+
+int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
+    p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows;
+    p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
+    p.n_long = m.n_long; p.n_chunks = m.n_chunks;
+    p.partial = nullptr;
+    if (m.n_rows == 0) return GNX_OK;
+    if (m.n_long > 0) {
+        int rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)p.C * sizeof(float));
+        if (rc != GNX_OK) return rc;
+        p.partial = g->partial;
+    }
+    const int vec = pick_vec(p);
+    const char *name;
+    if (vec == 4)      { name = launch_rows<4>(p, s); if (m.n_long) launch_long<4>(p, s); }
+    else if (vec == 2) { name = launch_rows<2>(p, s); if (m.n_long) launch_long<2>(p, s); }
+    else               { name = launch_rows<1>(p, s); if (m.n_long) launch_long<1>(p, s); }
+    g->last_kernel = name;
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+}  // namespace gnx
+
+extern "C" {
+
+int gnx_spmm(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx, int64_t C,
+             const float *d_H0, int64_t ldh0, float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm: invalid activation %d", act);
+    GNX_CHECK_ARG(d_diag == nullptr || g->a.n_rows == g->a.n_cols, "gnx_spmm: diag needs a square graph");
+    SpmmArgs p{};
+    p.vals = d_vals ? d_vals : g->raw_vals;
+    p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C;
+    return launch_spmm(g, g->a, p, (hipStream_t)stream);
+}
+
+int gnx_spmm_t(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx, int64_t C,
+               const float *d_H0, int64_t ldh0, float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm_t", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_t: invalid activation %d", act);
+    GNX_CHECK_ARG(d_diag == nullptr || g->a.n_rows == g->a.n_cols, "gnx_spmm_t: diag needs a square graph");
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    const float *src = d_vals ? d_vals : g->raw_vals;
+    if (g->a.nnz > 0)
+        hipLaunchKernelGGL(k_gather_vals, dim3(blocks_for(g->a.nnz, 256)), dim3(256), 0, s, src, g->t_perm, g->a.nnz, g->t_vals);
+    SpmmArgs p{};
+    p.vals = g->t_vals;
+    p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C;
+    return launch_spmm(g, g->t, p, s);
+}
+
+int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H, const float *d_H0, float a,
+                 int64_t C, int act, float *d_out, void *stream) {
+    GNX_CHECK_ARG(d_H0 != nullptr, "gnx_ppr_step: NULL H0");
+    return gnx_spmm(g, d_vals, d_diag, d_H, C, C, d_H0, C, (float)(1.0 - (double)a), a, act, d_out, C, stream);
+}
+
+int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0, float a, int K,
+                        int64_t C, float *d_out, float *d_work, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_appnp_propagate: NULL handle");
+    GNX_CHECK_ARG(K >= 0, "gnx_appnp_propagate: negative iteration count");
+    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols, "gnx_appnp_propagate: needs a square graph");
+    GNX_CHECK_ARG(d_H0 && d_out && (K < 2 || d_work), "gnx_appnp_propagate: NULL buffer");
+    GNX_CHECK_ARG(d_out != d_H0 && d_work != d_H0 && d_out != d_work, "gnx_appnp_propagate: H0, out and work must be distinct");
+    if (K == 0) {
+        GNX_HIP(hipMemcpyAsync(d_out, d_H0, (size_t)g->a.n_rows * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return GNX_OK;
+    }
+    const float *src = d_H0;
+    for (int k = 0; k < K; ++k) {
+        float *dst = ((K - 1 - k) % 2 == 0) ? d_out : d_work;
+        int rc = gnx_ppr_step(g, d_vals, d_diag, src, d_H0, a, C, GNX_ACT_NONE, dst, stream);
+        if (rc != GNX_OK) return rc;
+        src = dst;
+    }
+    return GNX_OK;
+}
+
+int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C, float *d_out, int64_t ldo,
+                    void *stream) {
+    GNX_CHECK_ARG(n_idx >= 0 && C >= 1 && ldx >= C && ldo >= C, "gnx_gather_rows: bad sizes");
+    if (n_idx == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_X && d_idx && d_out, "gnx_gather_rows: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && aligned(d_X, 16) && aligned(d_out, 16);
+    if (v4) hipLaunchKernelGGL(k_gather_rows<4>, dim3(blocks_for(n_idx, 4)), dim3(256), 0, s, d_X, ldx, d_idx, n_idx, (int)C, d_out, ldo);
+    else    hipLaunchKernelGGL(k_gather_rows<1>, dim3(blocks_for(n_idx, 4)), dim3(256), 0, s, d_X, ldx, d_idx, n_idx, (int)C, d_out, ldo);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+}  // extern "C"

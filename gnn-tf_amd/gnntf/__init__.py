@@ -1,0 +1,14 @@
+"""gnntf on MI355X: the reference's flat namespace (reference gnntf/__init__.py:1-2) over a
+HIP propagation path.  ``import gnntf`` then ``gnntf.APPNP``, ``gnntf.graph2adj``,
+``gnntf.NodeClassification`` ... work as in the reference's README and demos."""
+from .metrics import set_seed, acc
+from .params import WrappedVariable, VariableGenerator, set_default_device, default_device
+from .protocol import Layer, Layered
+from .blocks import Dense, Dropout, Activation, Branch, Resume, Concatenate, Tradeoff, relu, linear
+from .training import Predictor, Trainable
+from .tasks import NodeClassification
+from .sparse import SparseCOO, DeviceGraph, Adjacency, spmm, ppr_step, appnp_propagate, gather_rows, normalize, as_coo
+from .graph_io import create_nx_graph, adj2graph, graph2indices, graph2adj
+from .graph_model import GNN, PPRIteration, APPNP, GCNLayer, GCN
+
+__version__ = "0.1.0"

@@ -1,0 +1,83 @@
+"""ctypes binding of libgnx.so (include/gnx.h) -- the only way the package reaches the GPU.
+
+There is deliberately NO fallback: if the library is missing or a call fails, an Exception
+is raised.  Nothing here imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
+
+NORM = {"none": 0, "symmetric": 1, "bipartite": 2}
+EYE = {"none": 0, "before": 1, "after": 2}
+ACT_NONE, ACT_RELU = 0, 1
+
+# name -> (restype, argtypes); must list every symbol include/gnx.h declares
+SIGNATURES = {
+    "gnx_last_error": (c_char_p, []),
+    "gnx_version": (c_int, []),
+    "gnx_graph_create_coo": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "gnx_graph_create_csr": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "gnx_graph_destroy": (c_int, [c_void_p]),
+    "gnx_graph_info": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "gnx_graph_csr": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
+    "gnx_graph_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gnx_graph_normalize": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "gnx_graph_colsum": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
+    "gnx_degree_scale": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "gnx_graph_scale_values": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gnx_spmm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,
+                         c_int, c_void_p, c_int64, c_void_p]),
+    "gnx_spmm_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,
+                           c_int, c_void_p, c_int64, c_void_p]),
+    "gnx_ppr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
+    "gnx_appnp_propagate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_void_p, c_void_p,
+                                    c_void_p]),
+    "gnx_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gnx_graph_last_kernel": (c_char_p, [c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libgnx.so once; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Exception(f"gnntf: the HIP library {LIB_PATH} is missing -- build it with "
+                            f"`make -C gnn-tf_amd/csrc` (or __graft_entry__.build()); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().gnx_last_error()
+        raise Exception((msg.decode() if msg else "") or f"libgnx error {rc}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise Exception("gnntf: the propagation path runs on the GPU only (tensor on %s); there is no CPU "
+                            "fallback" % t.device)

@@ -1,0 +1,105 @@
+"""Graph architectures over the HIP propagation path: GNN (adjacency owner), PPRIteration,
+APPNP, GCNLayer, GCN.
+
+Mirrors reference gnntf/core/gnn/gnn.py:29-50, gnntf/core/gnn/architectures/filter.py:6-35
+and gnntf/core/gnn/architectures/gcn.py:77-113.  Where the reference calls
+tf.sparse.sparse_dense_matmul on a freshly re-normalised tf.sparse tensor, these layers call
+the fused gfx950 kernels through gnntf.sparse; the eval-mode normalised adjacency is
+computed once per (normalized, add_eye) and cached, because it is constant.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import sparse
+from .blocks import Dense, Dropout, linear, relu
+from .params import default_device
+from .protocol import Layer
+from .training import Trainable
+
+
+class GNN(Trainable):
+    """gnn.py:29-50."""
+
+    def __init__(self, graph, features, preprocessor: Layer = None):
+        super().__init__(features)
+        if isinstance(graph, sparse.DeviceGraph):
+            self.graph = graph
+        else:
+            self.graph = sparse.DeviceGraph(sparse.as_coo(graph), device=default_device())
+        self._adjacency_cache = dict()
+        if preprocessor is not None:
+            self.add(preprocessor)
+
+    def get_adjacency(self, graph_dropout=0.5, normalized="symmetric", add_eye="none"):
+        """Edge dropout (training mode only) -> optional +I -> D^-1/2 A D^-1/2 by column sums
+        (gnn.py:36-50), as one device call.  Returns an Adjacency for gnntf.spmm."""
+        if normalized not in ("symmetric", "bipartite", "none"):
+            raise Exception("Invalid matrix normalization")
+        if graph_dropout != 0 and self.is_training():
+            seed, stream = self._next_mask_stream()
+            return sparse.normalize(self.graph, normalized, add_eye, graph_dropout, seed, stream)
+        key = (normalized, add_eye)
+        if key not in self._adjacency_cache:
+            self._adjacency_cache[key] = sparse.normalize(self.graph, normalized, add_eye)
+        return self._adjacency_cache[key]
+
+
+class PPRIteration(Layer):
+    """One APPNP power-iteration step (filter.py:6-22): activation(dropout((A.H)(1-a) + H0 a))."""
+
+    def __build__(self, architecture: GNN, H0: Layer, restart_probability: float = 0.1, activation=linear,
+                  dropout: float = 0, graph_dropout: float = 0.5, restart_transform=linear):
+        self.restart_probability = restart_probability
+        self.H0 = H0
+        self.dropout = dropout
+        self.graph_dropout = graph_dropout
+        self.activation = activation
+        self.restart_transform = restart_transform
+        return architecture.top_shape()  # preserves the feature shape
+
+    def __forward__(self, architecture: GNN, features):
+        self.G = architecture.get_adjacency(self.graph_dropout)
+        a = self.restart_transform(self.restart_probability)
+        mixed = sparse.ppr_step(self.G, features, self.H0.value, a)
+        return self.activation(architecture.dropout(mixed, self.dropout))
+
+
+class APPNP(GNN):
+    """filter.py:25-35 -- https://arxiv.org/pdf/1810.05997.pdf"""
+
+    def __init__(self, G, features, num_classes: int, a: float = 0.1, latent_dims=[64], iterations=10,
+                 dropout=0.6, graph_dropout=0.5, activation=linear, **kwargs):
+        super().__init__(G, features, **kwargs)
+        self.add(Dropout(0.5))
+        for latent_dim in latent_dims:
+            self.add(Dense(latent_dim, activation=relu, dropout=dropout))
+        H0 = self.add(Dense(num_classes, regularize=False))
+        for _ in range(iterations):
+            self.add(PPRIteration(H0, self.create_var() if a is None else a, graph_dropout=graph_dropout, activation=activation))
+
+
+class GCNLayer(Layer):
+    """gcn.py:77-89: dropout(activation((A.X).W + b)) -- aggregation first, at the input width."""
+
+    def __build__(self, gcn, outputs: int, activation=relu, bias: bool = True, dropout: float = 0, graph_dropout: float = 0):
+        self.W = gcn.create_var((gcn.top_shape()[1], outputs))
+        self.b = gcn.create_var((1, outputs), "zero") if bias else 0
+        self.activation = activation
+        self.dropout = dropout
+        self.graph_dropout = graph_dropout
+        return (gcn.top_shape()[0], outputs)
+
+    def __forward__(self, gcn, features):
+        aggregated_features = sparse.spmm(gcn.get_adjacency(self.graph_dropout), features)
+        return gcn.dropout(self.activation(torch.matmul(aggregated_features, self.W) + self.b), self.dropout)
+
+
+class GCN(GNN):
+    """gcn.py:108-113 (the last layer keeps the default relu, as in the reference)."""
+
+    def __init__(self, G, features, num_classes, latent_dims=[64], layer_type=GCNLayer, **kwargs):
+        super().__init__(G, features, **kwargs)
+        for latent_dim in latent_dims:
+            self.add(layer_type(latent_dim, graph_dropout=0.5, dropout=0.5))
+        self.add(layer_type(num_classes))

@@ -1,0 +1,245 @@
+"""Sparse containers and the differentiable propagation ops over libgnx.so.
+
+Stands where the reference uses tf.sparse.SparseTensor and tf.sparse.sparse_dense_matmul
+(reference gnntf/core/gnn/graph_manipulation.py:31, gnntf/core/gnn/architectures/filter.py:19,
+gnntf/core/gnn/architectures/gcn.py:88).
+"""
+from __future__ import annotations
+
+from ctypes import byref, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+class SparseCOO:
+    """What graph2adj returns: an UNSORTED COO that may hold duplicates, exactly like the
+    tf.sparse.SparseTensor of the reference (graph_manipulation.py:31).
+    ``indices`` int64 [nnz, 2], ``values`` float32 [nnz], ``dense_shape`` (rows, cols)."""
+
+    def __init__(self, indices, values, dense_shape):
+        if isinstance(indices, torch.Tensor):
+            self.indices = indices.to(torch.int64).reshape(-1, 2)
+            self.values = torch.as_tensor(values, dtype=torch.float32, device=self.indices.device).reshape(-1)
+        else:
+            self.indices = torch.from_numpy(np.ascontiguousarray(np.asarray(indices, dtype=np.int64).reshape(-1, 2)))
+            self.values = torch.from_numpy(np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1)))
+        if self.indices.shape[0] != self.values.shape[0]:
+            raise Exception("SparseCOO: indices and values disagree on the number of entries")
+        self.dense_shape = (int(dense_shape[0]), int(dense_shape[1]))
+
+    @property
+    def shape(self):
+        return self.dense_shape
+
+    def to(self, device):
+        return SparseCOO(self.indices.to(device), self.values.to(device), self.dense_shape)
+
+
+def as_coo(graph) -> SparseCOO:
+    """Accepts a SparseCOO, a torch sparse COO tensor, a scipy sparse matrix or an
+    (indices, values, shape) triple."""
+    if isinstance(graph, SparseCOO):
+        return graph
+    if isinstance(graph, torch.Tensor) and graph.is_sparse:
+        return SparseCOO(graph._indices().t().contiguous(), graph._values(), graph.shape)
+    if hasattr(graph, "tocoo"):
+        m = graph.tocoo()
+        return SparseCOO(np.stack([m.row, m.col], axis=1), m.data, m.shape)
+    if isinstance(graph, (tuple, list)) and len(graph) == 3:
+        return SparseCOO(*graph)
+    raise Exception("Unsupported graph container: " + str(type(graph)))
+
+
+class DeviceGraph:
+    """Owner of a gnx_graph_t (device CSR built from the COO)."""
+
+    def __init__(self, coo: SparseCOO = None, device=None, csr=None):
+        self._h = c_void_p()
+        lib = nat.lib()
+        if csr is not None:
+            rowptr, colidx, vals, shape = csr
+            nat.require_cuda(rowptr, colidx, vals)
+            self.device = rowptr.device
+            self._keep = (rowptr.contiguous(), colidx.contiguous(), vals.contiguous())
+            with torch.cuda.device(self.device):
+                nat.check(lib.gnx_graph_create_csr(shape[0], shape[1], self._keep[1].numel(), nat.ptr(self._keep[0]),
+                                                   nat.ptr(self._keep[1]), nat.ptr(self._keep[2]), nat.current_stream(),
+                                                   byref(self._h)))
+            self._keep = None
+        else:
+            device = torch.device(device if device is not None else "cuda")
+            if device.type != "cuda":
+                raise Exception("gnntf: graphs live on the GPU only; there is no CPU fallback")
+            self.device = device
+            idx = coo.indices.to(device).contiguous()
+            val = coo.values.to(device).contiguous()
+            with torch.cuda.device(device):
+                nat.check(lib.gnx_graph_create_coo(coo.dense_shape[0], coo.dense_shape[1], idx.shape[0], nat.ptr(idx),
+                                                   nat.ptr(val), nat.current_stream(), byref(self._h)))
+        n_rows, n_cols, nnz_e, nnz_c = c_int64(), c_int64(), c_int64(), c_int64()
+        nat.check(lib.gnx_graph_info(self._h, byref(n_rows), byref(n_cols), byref(nnz_e), byref(nnz_c)))
+        self.n_rows, self.n_cols = n_rows.value, n_cols.value
+        self.nnz_entries, self.nnz = nnz_e.value, nnz_c.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def csr_arrays(self, with_rows=False):
+        """Copies of (rowptr int64, colidx int32, raw values float32[, rowidx int32])."""
+        rowptr = torch.empty(self.n_rows + 1, dtype=torch.int64, device=self.device)
+        colidx = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+        vals = torch.empty(self.nnz, dtype=torch.float32, device=self.device)
+        rows = torch.empty(self.nnz, dtype=torch.int32, device=self.device) if with_rows else None
+        with torch.cuda.device(self.device):
+            nat.check(nat.lib().gnx_graph_export(self._h, nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(vals), nat.ptr(rows),
+                                                 nat.current_stream()))
+        return (rowptr, colidx, vals, rows) if with_rows else (rowptr, colidx, vals)
+
+    def last_kernel(self) -> str:
+        return (nat.lib().gnx_graph_last_kernel(self._h) or b"").decode()
+
+    def __del__(self):
+        try:
+            if self._h:
+                nat.lib().gnx_graph_destroy(self._h)
+                self._h = c_void_p()
+        except Exception:
+            pass
+
+
+class Adjacency:
+    """What GNN.get_adjacency returns: a device graph + one set of (normalised, possibly
+    dropped-out) values + the diagonal weight of an added identity.  Usable with
+    ``gnntf.spmm(adj, H)`` wherever the reference calls tf.sparse.sparse_dense_matmul."""
+
+    def __init__(self, graph: DeviceGraph, vals: torch.Tensor = None, diag: torch.Tensor = None):
+        self.graph = graph
+        self.vals = vals
+        self.diag = diag
+
+    @property
+    def shape(self):
+        return (self.graph.n_rows, self.graph.n_cols)
+
+
+def normalize(graph: DeviceGraph, normalized="symmetric", add_eye="none", dropout=0.0, seed=0, stream_id=0) -> Adjacency:
+    """GNN.get_adjacency on the device (reference gnn.py:36-50)."""
+    if normalized not in nat.NORM:
+        raise Exception("Invalid matrix normalization")
+    if add_eye not in nat.EYE:
+        raise Exception("Invalid add_eye option")
+    vals = torch.empty(graph.nnz, dtype=torch.float32, device=graph.device)
+    diag = torch.empty(graph.n_rows, dtype=torch.float32, device=graph.device) if add_eye != "none" else None
+    with torch.cuda.device(graph.device):
+        nat.check(nat.lib().gnx_graph_normalize(graph.handle, nat.NORM[normalized], nat.EYE[add_eye], float(dropout),
+                                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFFFFFFFFFF,
+                                                nat.ptr(vals), nat.ptr(diag), nat.current_stream()))
+    return Adjacency(graph, vals, diag)
+
+
+def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype != torch.float32:
+        x = x.float()
+    if x.dim() != 2:
+        raise Exception("propagation expects a 2-D feature matrix")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    return x
+
+
+def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False):
+    g = adj.graph
+    nat.require_cuda(X, H0)
+    X = _as_f32_rows(X)
+    rows_in = g.n_rows if transposed else g.n_cols
+    rows_out = g.n_cols if transposed else g.n_rows
+    if X.shape[0] != rows_in:
+        raise Exception(f"spmm: features have {X.shape[0]} rows, adjacency expects {rows_in}")
+    C = X.shape[1]
+    out = torch.empty((rows_out, C), dtype=torch.float32, device=X.device)
+    if H0 is not None:
+        H0 = _as_f32_rows(H0)
+        if tuple(H0.shape) != (rows_out, C):
+            raise Exception("spmm: H0 shape mismatch")
+    fn = nat.lib().gnx_spmm_t if transposed else nat.lib().gnx_spmm
+    with torch.cuda.device(X.device):
+        nat.check(fn(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
+                     H0.stride(0) if H0 is not None else 0, float(beta), float(alpha), int(act), nat.ptr(out), out.stride(0),
+                     nat.current_stream()))
+    return out
+
+
+class _SpMM(torch.autograd.Function):
+    """out = A . X ; backward dX = A^T . g (what tf.GradientTape derives for filter.py:19)."""
+
+    @staticmethod
+    def forward(ctx, X, adj):
+        ctx.adj = adj
+        return _launch(adj, X, None, 1.0, 0.0, nat.ACT_NONE)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _launch(ctx.adj, g.contiguous(), None, 1.0, 0.0, nat.ACT_NONE, transposed=True), None
+
+
+class _PPRStep(torch.autograd.Function):
+    """out = (A . H)*(1-a) + H0*a in one kernel (filter.py:19-21);
+    backward dH = (1-a) A^T g, dH0 = a g."""
+
+    @staticmethod
+    def forward(ctx, H, H0, adj, a):
+        ctx.adj, ctx.a = adj, a
+        return _launch(adj, H, H0, 1.0 - a, a, nat.ACT_NONE)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gH = _launch(ctx.adj, g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True) if ctx.needs_input_grad[0] else None
+        gH0 = g * ctx.a if ctx.needs_input_grad[1] else None
+        return gH, gH0, None, None
+
+
+def spmm(adj: Adjacency, X: torch.Tensor) -> torch.Tensor:
+    """Drop-in for tf.sparse.sparse_dense_matmul(adj, X); differentiable w.r.t. X."""
+    return _SpMM.apply(X, adj)
+
+
+def ppr_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a) -> torch.Tensor:
+    """One fused PPRIteration step.  ``a`` may be a float (fused kernel) or a tensor
+    (a trainable teleport probability: un-fused so autograd reaches it)."""
+    if isinstance(a, torch.Tensor):
+        return spmm(adj, H) * (1 - a) + H0 * a
+    return _PPRStep.apply(H, H0, adj, float(a))
+
+
+def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations: int = 10) -> torch.Tensor:
+    """The eval-mode K-iteration loop as ONE library call with two ping-pong buffers
+    (no autograd, no per-layer .value caching) -- the measured hot path."""
+    g = adj.graph
+    nat.require_cuda(H0)
+    H0 = _as_f32_rows(H0).contiguous()
+    if g.n_rows != g.n_cols or H0.shape[0] != g.n_rows:
+        raise Exception("appnp_propagate: needs a square graph matching H0")
+    out = torch.empty_like(H0)
+    work = torch.empty_like(H0) if iterations > 1 else None
+    with torch.cuda.device(H0.device):
+        nat.check(nat.lib().gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(H0), float(a),
+                                                int(iterations), H0.shape[1], nat.ptr(out), nat.ptr(work),
+                                                nat.current_stream()))
+    return out
+
+
+def gather_rows(X: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """out[r] = X[idx[r]] through the library's halo-packing kernel."""
+    nat.require_cuda(X, idx)
+    X = _as_f32_rows(X)
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty((idx.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        nat.check(nat.lib().gnx_gather_rows(nat.ptr(X), X.stride(0), nat.ptr(idx), idx.numel(), X.shape[1], nat.ptr(out),
+                                            out.stride(0), nat.current_stream()))
+    return out

@@ -1,0 +1,40 @@
+"""NodeClassification, the consumer of the propagated logits.
+Mirrors reference gnntf/core/gnn/graph_predictor.py:10-31 (the link-prediction tasks in
+that file belong to a different path)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .training import Predictor
+
+
+def _index(nodes, device):
+    return torch.as_tensor(np.asarray(nodes), dtype=torch.int64, device=device)
+
+
+class NodeClassification(Predictor):
+    def __init__(self, nodes, labels=None, loss_transform=None):
+        self.nodes = nodes
+        self.labels = labels
+        self.loss_transform = loss_transform
+
+    def predict(self, features):
+        """argmax over the rows of ``nodes`` (graph_predictor.py:16-17)."""
+        return torch.argmax(features[_index(self.nodes, features.device)], dim=1)
+
+    def loss(self, features):
+        if self.labels is None:
+            raise Exception("Evaluation requires node labels")
+        if self.loss_transform is not None:
+            features = self.loss_transform(features)
+        predictions = torch.log_softmax(features[_index(self.nodes, features.device)], dim=1)
+        # SparseCategoricalCrossentropy(from_logits=True) on top of the log-softmax (graph_predictor.py:24-25)
+        return torch.nn.functional.cross_entropy(predictions, _index(self.labels, features.device))
+
+    def evaluate(self, features):
+        if self.labels is None:
+            raise Exception("Evaluation requires node labels")
+        predictions = torch.argmax(features[_index(self.nodes, features.device)], dim=1)
+        wrong = torch.count_nonzero(predictions - _index(self.labels, features.device)).item()
+        return 1 - wrong / predictions.shape[0]

@@ -1,0 +1,146 @@
+/* gnx.h -- C ABI of libgnx.so: gnntf's sparse propagation hot path on MI355X (gfx950).
+ *
+ * The reference (gnntf 0.0.20, paths relative to /root/reference) has NO FFI of its own:
+ * the path is Python calling TensorFlow eager ops.  Each entry point below therefore
+ * replaces a TensorFlow call site (or a short run of them) in the reference's Python, and
+ * is what a ctypes binding inside gnntf would bind (INTEGRATION.md shows that binding).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM of the current HIP device); the
+ *     library borrows it for the duration of the call and never frees it;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     enqueued on it and the call returns without waiting, except the graph constructors,
+ *     which synchronise that stream (they read sizes back to size their allocations);
+ *   - return value: 0 = ok, < 0 = error code below; gnx_last_error() then holds a
+ *     thread-local message.  Nothing throws across this boundary;
+ *   - a gnx_graph_t owns its device-side index arrays (hipMalloc) until gnx_graph_destroy;
+ *     it is not re-entrant: use one handle from one stream at a time;
+ *   - features are row-major float32, leading dimension (`ld*`, in elements) given per call.
+ */
+#ifndef GNX_H
+#define GNX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gnx_graph *gnx_graph_t;
+
+enum { GNX_OK = 0, GNX_ERR_INVALID = -1, GNX_ERR_HIP = -2, GNX_ERR_ALLOC = -3, GNX_ERR_UNSUPPORTED = -4 };
+
+/* `normalized` argument of GNN.get_adjacency (gnntf/core/gnn/gnn.py:36,40-47) */
+enum { GNX_NORM_NONE = 0, GNX_NORM_SYMMETRIC = 1, GNX_NORM_BIPARTITE = 2 };
+/* `add_eye` argument of GNN.get_adjacency (gnn.py:36,38-39,48-49) */
+enum { GNX_EYE_NONE = 0, GNX_EYE_BEFORE = 1, GNX_EYE_AFTER = 2 };
+/* epilogue activation: identity (filter.py:8 default) or relu (gcn.py:78 default) */
+enum { GNX_ACT_NONE = 0, GNX_ACT_RELU = 1 };
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *gnx_last_error(void);
+/* ABI version: major*10000 + minor*100 + patch. */
+int gnx_version(void);
+
+/* ---- graph construction ------------------------------------------------------------
+ * Replaces tf.sparse.SparseTensor(indices, values, shape) built by graph2adj
+ * (gnntf/core/gnn/graph_manipulation.py:24-31): d_indices is int64 [nnz, 2] row-major
+ * (row, col) pairs -- UNSORTED, duplicates allowed -- d_values float32 [nnz].
+ * The handle keeps every entry (sorted by (row, col), input order kept among duplicates,
+ * so per-entry edge dropout follows layered.py:47-50) plus the coalesced CSR in which
+ * duplicates are summed (what tf.sparse.sparse_dense_matmul / reduce_sum compute).
+ * Fails with GNX_ERR_INVALID on an index outside the shape. */
+int gnx_graph_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_indices,
+                         const float *d_values, void *stream, gnx_graph_t *out);
+
+/* Same from a ready CSR (rows ascending, columns ascending and unique inside a row):
+ * d_rowptr int64 [n_rows+1], d_colidx int32 [nnz], d_values float32 [nnz].  Used for the
+ * column-remapped shard of a vertex-partitioned graph. */
+int gnx_graph_create_csr(int64_t n_rows, int64_t n_cols, int64_t nnz, const int64_t *d_rowptr,
+                         const int32_t *d_colidx, const float *d_values, void *stream, gnx_graph_t *out);
+
+int gnx_graph_destroy(gnx_graph_t g);
+
+/* Sizes: stored COO entries and coalesced (unique (row, col)) entries. */
+int gnx_graph_info(gnx_graph_t g, int64_t *n_rows, int64_t *n_cols, int64_t *nnz_entries,
+                   int64_t *nnz_coalesced);
+
+/* Borrowed device pointers to the coalesced CSR (valid until destroy):
+ * rowptr int64 [n_rows+1], colidx int32 [nnz_coalesced], raw summed values float32. */
+int gnx_graph_csr(gnx_graph_t g, const int64_t **d_rowptr, const int32_t **d_colidx,
+                  const float **d_raw_values);
+/* Copies of the coalesced CSR into caller-owned device buffers (any may be NULL = skip):
+ * rowptr int64 [n_rows+1], colidx int32 [nnz_coalesced], raw values float32 [nnz_coalesced],
+ * rowidx int32 [nnz_coalesced] (the row of every coalesced entry).  Stream-ordered. */
+int gnx_graph_export(gnx_graph_t g, int64_t *d_rowptr_out, int32_t *d_colidx_out, float *d_raw_values_out,
+                     int32_t *d_rowidx_out, void *stream);
+
+/* ---- normalisation: GNN.get_adjacency (gnn.py:36-50) --------------------------------
+ * One call = sparse_dropout (layered.py:47-50; only when dropout_p > 0 -- the caller passes
+ * 0 in eval mode) -> add_eye "before" -> symmetric / bipartite scaling by COLUMN sums with
+ * divide_no_nan -> add_eye "after".  Writes the values of A_hat in coalesced-CSR order to
+ * d_vals_out [nnz_coalesced].  The identity added by add_eye is returned as a per-row
+ * diagonal weight in d_diag_out [n_rows] (pass it to gnx_spmm); d_diag_out may be NULL when
+ * add_eye == GNX_EYE_NONE.  Dropout draws come from the counter RNG keyed by (seed,
+ * stream_id, row, col, duplicate rank), so they do not depend on how the graph is sharded.
+ * Requires a square graph for symmetric/bipartite. */
+int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed,
+                        uint64_t stream_id, float *d_vals_out, float *d_diag_out, void *stream);
+
+/* The three steps separately, for vertex-partitioned graphs where column sums need a
+ * cross-rank all-reduce in between:
+ *   colsum: d_colsum_out[j] = sum_i v_ij over this handle's rows (tf.sparse.reduce_sum
+ *           axis=0, gnn.py:41,44), v = dropped raw values; fixed summation order.
+ *   degree_scale: in place d[j] <- divide_no_nan(1, sqrt(d[j] + eye)) (symmetric) or
+ *           divide_no_nan(1, d[j] + eye) (bipartite); eye = 1 for add_eye "before".
+ *   scale_values: d_vals_out[k] = row_scale[row_k] * v_k * col_scale[col_k]; either scale
+ *           may be NULL (= 1).  (gnn.py:42,45) */
+int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id,
+                     float *d_colsum_out, void *stream);
+int gnx_degree_scale(float *d_deg, int64_t n, int normalized, int add_eye_before, void *stream);
+int gnx_graph_scale_values(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id,
+                           const float *d_row_scale, const float *d_col_scale, float *d_vals_out,
+                           void *stream);
+
+/* ---- the hot path ---------------------------------------------------------------------
+ * gnx_spmm: out[i,:] = act( beta * ( sum_j A[i,j] X[j,:] + diag[i] X[i,:] ) + alpha * H0[i,:] )
+ *   - replaces tf.sparse.sparse_dense_matmul (filter.py:19, gcn.py:88) and, with
+ *     beta = 1-a, alpha = a, the residual mix fused behind it (filter.py:20-21) and the
+ *     optional activation (filter.py:22);
+ *   - d_vals: values in coalesced-CSR order (from gnx_graph_normalize), NULL = raw values;
+ *   - d_diag: per-row diagonal weight or NULL; d_H0 may be NULL (then alpha is ignored);
+ *   - X is [n_cols, C], out and H0 are [n_rows, C]; out must not alias X.
+ * gnx_spmm_t: the same with the transposed matrix (out is [n_cols, C], X and H0 index by
+ *   the other side) -- the backward of gnx_spmm (what tf.GradientTape derives,
+ *   trainable.py:70-78).  d_vals are still given in coalesced-CSR order of A. */
+int gnx_spmm(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx,
+             int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
+             float *d_out, int64_t ldo, void *stream);
+int gnx_spmm_t(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx,
+               int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
+               float *d_out, int64_t ldo, void *stream);
+
+/* One PPRIteration.__forward__ (filter.py:17-22) with a fixed adjacency:
+ * out = act( (A_hat . H)*(1-a) + H0*a ).  Thin wrapper over gnx_spmm. */
+int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H,
+                 const float *d_H0, float a, int64_t C, int act, float *d_out, void *stream);
+
+/* The K-iteration loop of APPNP in eval mode (filter.py:34-35 with a constant A_hat):
+ * H <- H0; repeat K times H <- (A_hat . H)*(1-a) + H0*a.  All matrices [n, C] contiguous
+ * (square graph).  d_work is a caller-provided scratch [n, C]; the result lands in d_out.
+ * d_out, d_work and d_H0 must be distinct buffers. */
+int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0,
+                        float a, int K, int64_t C, float *d_out, float *d_work, void *stream);
+
+/* Halo packing for the vertex-partitioned path: out[r,:] = X[idx[r],:], idx int64 [n_idx]. */
+int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,
+                    float *d_out, int64_t ldo, void *stream);
+
+/* Name of the SpMM kernel the last gnx_spmm/_t call on this handle dispatched (static
+ * string; for profiles and tests). */
+const char *gnx_graph_last_kernel(gnx_graph_t g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNX_H */

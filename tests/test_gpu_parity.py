@@ -1,0 +1,314 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, on the GPU box.
+Tolerance: float32 logits within rtol 1e-4 (BASELINE.json north_star) + atol 1e-5 for sums that
+cancel; argmax identical on every row; integer structure (CSR) bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import graphs
+from oracle import gnntf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def gnntf():
+    import gnntf
+    gnntf.set_default_device("cuda:0")
+    yield gnntf
+    gnntf.set_default_device(None)
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def make_graph(gnntf, coo, vals, shape):
+    return gnntf.DeviceGraph(gnntf.SparseCOO(coo, vals, shape), device="cuda:0")
+
+
+# ---- A0: COO -> coalesced CSR is bit-exact ------------------------------------------------------
+@pytest.mark.parametrize("shape,nnz", [((1, 1), 1), ((7, 5), 23), ((300, 300), 5000), ((2000, 1500), 60000)])
+def test_csr_structure_bit_exact(gnntf, shape, nnz):
+    coo, vals, shape = graphs.random_coo(shape[0], shape[1], nnz, seed=nnz, weighted=True, dup_frac=0.3)
+    g = make_graph(gnntf, coo, vals, shape)
+    rowptr, colidx, cvals, rows = g.csr_arrays(with_rows=True)
+    wr, wc, wv = orc.coo_to_csr_coalesced(coo, vals, shape)
+    assert g.nnz_entries == len(vals) and g.nnz == len(wc)
+    np.testing.assert_array_equal(rowptr.cpu().numpy(), wr)
+    np.testing.assert_array_equal(colidx.cpu().numpy(), wc)
+    np.testing.assert_array_equal(cvals.cpu().numpy(), wv)     # duplicates summed in input order: same float32 bits
+    np.testing.assert_array_equal(rows.cpu().numpy(), np.repeat(np.arange(shape[0]), np.diff(wr)))
+
+
+def test_empty_and_invalid_graphs(gnntf):
+    g = make_graph(gnntf, np.zeros((0, 2), dtype=np.int64), np.zeros(0, dtype=np.float32), (5, 5))
+    assert g.nnz == 0
+    adj = gnntf.normalize(g, "symmetric")
+    H = torch.ones(5, 3, device="cuda")
+    assert float(gnntf.spmm(adj, H).abs().sum()) == 0
+    out = gnntf.appnp_propagate(adj, H, a=0.25, iterations=3)
+    np.testing.assert_allclose(out.cpu().numpy(), 0.25 * np.ones((5, 3)), rtol=1e-7)
+    with pytest.raises(Exception, match="outside the 4 x 4 shape"):
+        make_graph(gnntf, np.array([[0, 1], [4, 0]]), np.ones(2, dtype=np.float32), (4, 4))
+    with pytest.raises(Exception, match="Invalid matrix normalization"):
+        gnntf.normalize(g, "row")
+    with pytest.raises(Exception, match="expects 5"):
+        gnntf.spmm(adj, torch.ones(6, 3, device="cuda"))
+
+
+# ---- A2: get_adjacency -------------------------------------------------------------------------------
+@pytest.mark.parametrize("norm", ["symmetric", "bipartite", "none"])
+@pytest.mark.parametrize("eye", ["none", "before", "after"])
+def test_normalize_options(gnntf, norm, eye):
+    coo, vals, shape = graphs.random_coo(257, 257, 3000, seed=21, weighted=True, dup_frac=0.25)
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, norm, eye)
+    H = np.random.default_rng(1).standard_normal((257, 12)).astype(np.float32)
+    ai, av = orc.get_adjacency(coo, vals, shape, normalized=norm, add_eye=eye, dtype=np.float64)
+    want = orc.sparse_dense_matmul(ai, av, shape, H.astype(np.float64))
+    np.testing.assert_allclose(gnntf.spmm(adj, dev(H)).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+def test_hand_graphs(gnntf):
+    """KAT-2 on the device: isolated nodes -> a*H0; doubled COO == single COO; directed column-sum rule."""
+    idx, vals, shape = orc.graph2adj(range(8), [(0, i) for i in range(1, 6)])
+    adj = gnntf.normalize(make_graph(gnntf, idx, vals, shape), "symmetric")
+    H0 = np.arange(16, dtype=np.float32).reshape(8, 2)
+    out = gnntf.appnp_propagate(adj, dev(H0), a=0.25, iterations=3).cpu().numpy()
+    np.testing.assert_allclose(out, orc.appnp_propagate(idx, vals, shape, H0, a=0.25, iterations=3), rtol=1e-6)
+    np.testing.assert_array_equal(out[6:], np.float32(0.25) * H0[6:])
+    und = [(0, 1), (1, 2), (2, 0), (2, 3)]
+    i1, v1, s4 = orc.graph2adj(range(4), und)
+    i2, v2, _ = orc.graph2adj(range(4), und + [(v, u) for u, v in und])
+    a1, a2 = gnntf.normalize(make_graph(gnntf, i1, v1, s4)), gnntf.normalize(make_graph(gnntf, i2, v2, s4))
+    np.testing.assert_allclose(a1.vals.cpu().numpy(), a2.vals.cpu().numpy(), rtol=1e-7)
+    i3, v3, s3 = orc.graph2adj(range(3), [(0, 1), (0, 2), (1, 2)], weights=[2.0, 3.0, 4.0], directed=True)
+    a3 = gnntf.normalize(make_graph(gnntf, i3, v3, s3))
+    _, want = orc.get_adjacency(i3, v3, s3)
+    np.testing.assert_allclose(a3.vals.cpu().numpy(), want, rtol=1e-7)   # row 0 scales by colsum 0 -> all zero
+    assert float(a3.vals[:2].abs().sum()) == 0
+
+
+# ---- A3/A4: SpMM + fused mix over every dispatch class ----------------------------------------------
+@pytest.mark.parametrize("C", [1, 3, 7, 8, 16, 40, 64, 100, 128, 192, 256, 260, 512, 1030])
+def test_ppr_step_all_widths(gnntf, C):
+    coo, vals, shape = graphs.rmat_symmetric_coo(3000, 30000, seed=C)
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, "symmetric")
+    rng = np.random.default_rng(C)
+    H = rng.uniform(-1, 1, size=(3000, C)).astype(np.float32)
+    H0 = rng.uniform(-1, 1, size=(3000, C)).astype(np.float32)
+    ai, av = orc.get_adjacency(coo, vals, shape)
+    want = orc.ppr_iteration(ai, av, shape, H, H0, a=0.1)
+    got = gnntf.ppr_step(adj, dev(H), dev(H0), 0.1).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(gnntf.spmm(adj, dev(H)).cpu().numpy(), orc.sparse_dense_matmul(ai, av, shape, H), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("C", [7, 64, 256])
+def test_long_rows_and_ragged(gnntf, C):
+    """Hub rows far above LONG_ROW (512) entries, empty rows, a rectangular matrix, ragged tails."""
+    rng = np.random.default_rng(C)
+    n_rows, n_cols = 700, 5000
+    hub = np.stack([np.zeros(4999, dtype=np.int64), rng.permutation(n_cols)[:4999]], axis=1)      # one 4999-entry row
+    hub2 = np.stack([np.full(513, 3, dtype=np.int64), rng.permutation(n_cols)[:513]], axis=1)      # just over the threshold
+    edge = np.stack([np.full(512, 5, dtype=np.int64), rng.permutation(n_cols)[:512]], axis=1)      # exactly at it
+    rest = np.stack([rng.integers(10, n_rows, size=6000), rng.integers(n_cols, size=6000)], axis=1)
+    coo = np.concatenate([hub, hub2, edge, rest])
+    vals = rng.uniform(0.5, 1.5, size=len(coo)).astype(np.float32)
+    g = make_graph(gnntf, coo, vals, (n_rows, n_cols))
+    X = rng.uniform(-1, 1, size=(n_cols, C)).astype(np.float32)
+    H0 = rng.uniform(-1, 1, size=(n_rows, C)).astype(np.float32)
+    adj = gnntf.Adjacency(g)            # raw values
+    want = orc.sparse_dense_matmul(coo, vals.astype(np.float64), (n_rows, n_cols), X.astype(np.float64))
+    got = gnntf.spmm(adj, dev(X)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4)
+    assert (got[1] == 0).all()          # empty row
+    # transposed product exercises long COLUMNS of the same matrix
+    G = rng.uniform(-1, 1, size=(n_rows, C)).astype(np.float32)
+    from gnntf.sparse import _launch
+    got_t = _launch(adj, dev(G), None, 1.0, 0.0, 0, transposed=True).cpu().numpy()
+    want_t = orc.sparse_dense_matmul(coo[:, ::-1], vals.astype(np.float64), (n_cols, n_rows), G.astype(np.float64))
+    np.testing.assert_allclose(got_t, want_t, rtol=RTOL, atol=1e-4)
+
+
+def test_reproducible_bitwise(gnntf):
+    coo, vals, shape = graphs.rmat_symmetric_coo(5000, 80000, seed=3)
+    adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape))
+    H0 = dev(np.random.default_rng(0).uniform(-1, 1, size=(5000, 256)).astype(np.float32))
+    a = gnntf.appnp_propagate(adj, H0, 0.1, 10)
+    b = gnntf.appnp_propagate(adj, H0, 0.1, 10)
+    assert torch.equal(a, b)
+    step = H0
+    for _ in range(10):
+        step = gnntf.ppr_step(adj, step, H0, 0.1)
+    assert torch.equal(a, step)          # the fused K loop == K single steps
+
+
+def test_closed_form_on_device(gnntf):
+    coo, vals, shape = graphs.random_coo(150, 150, 1200, seed=5, weighted=True)
+    H0 = np.random.default_rng(0).standard_normal((150, 5)).astype(np.float32)
+    A = orc.to_dense(coo, vals, shape)
+    d = A.sum(axis=0)
+    D = np.where(d > 0, 1 / np.sqrt(np.where(d > 0, d, 1)), 0)
+    want = orc.appnp_closed_form(D[:, None] * A * D[None, :], H0, 0.1, 10)
+    adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape))
+    np.testing.assert_allclose(gnntf.appnp_propagate(adj, dev(H0), 0.1, 10).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+def test_strided_inputs_and_gather(gnntf):
+    coo, vals, shape = graphs.rmat_symmetric_coo(1000, 8000, seed=8)
+    adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape))
+    big = dev(np.random.default_rng(1).uniform(-1, 1, size=(1000, 96)).astype(np.float32))
+    view = big[:, 16:80]                # leading dimension 96, width 64, 64-byte offset
+    ai, av = orc.get_adjacency(coo, vals, shape)
+    want = orc.sparse_dense_matmul(ai, av, shape, view.cpu().numpy())
+    np.testing.assert_allclose(gnntf.spmm(adj, view).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    odd = big[:, 1:8]                   # unaligned: scalar path
+    np.testing.assert_allclose(gnntf.spmm(adj, odd).cpu().numpy(), orc.sparse_dense_matmul(ai, av, shape, odd.cpu().numpy()),
+                               rtol=RTOL, atol=ATOL)
+    idx = torch.tensor([5, 0, 999, 5], device="cuda")
+    assert torch.equal(gnntf.gather_rows(big, idx), big[idx])
+    assert torch.equal(gnntf.gather_rows(odd, idx), odd[idx])
+
+
+# ---- training mode: dropout masks, renormalisation, backward ---------------------------------------------
+def test_dropout_masks_match_oracle_and_golden(gnntf, golden_dir):
+    z = np.load(os.path.join(golden_dir, "dropout_masks.npz"))
+    coo, vals, n = z["coo"].astype(np.int64), z["vals"], int(z["n"])
+    g = make_graph(gnntf, coo, vals, (n, n))
+    for stream in (0, 7):
+        adj = gnntf.normalize(g, "symmetric", "none", dropout=float(z["p"]), seed=int(z["seed"]), stream_id=stream)
+        _, _, want = orc.coo_to_csr_coalesced(coo, z[f"adj_vals_{stream}"], (n, n))
+        got = adj.vals.cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+        assert ((got == 0) == (want == 0)).all()       # exactly the same entries dropped
+        raw = gnntf.normalize(g, "none", "none", dropout=float(z["p"]), seed=int(z["seed"]), stream_id=stream)
+        _, _, want_raw = orc.coo_to_csr_coalesced(coo, np.where(z[f"keep_{stream}"], vals * np.float32(2), np.float32(0)), (n, n))
+        np.testing.assert_array_equal(raw.vals.cpu().numpy(), want_raw)
+
+
+def test_dropout_larger_graph(gnntf):
+    coo, vals, shape = graphs.cora_shaped(seed=1)[:3]
+    g = make_graph(gnntf, coo, vals, shape)
+    assert g.nnz_entries == 21112 and g.nnz == 10556
+    adj = gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=7, stream_id=11)
+    ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=0.5, training=True, seed=7, stream=11)
+    H = np.random.default_rng(0).standard_normal((shape[0], 7)).astype(np.float32)
+    np.testing.assert_allclose(gnntf.spmm(adj, dev(H)).cpu().numpy(), orc.sparse_dense_matmul(ai, av, shape, H), rtol=RTOL, atol=ATOL)
+    # per-entry dropout on the doubled COO: coalesced multipliers are 0, 2 or 4 (x the raw 1.0)
+    raw = gnntf.normalize(g, "none", "none", dropout=0.5, seed=7, stream_id=11).vals.cpu().numpy()
+    assert set(np.unique(raw).tolist()) == {0.0, 2.0, 4.0}
+
+
+@pytest.mark.parametrize("C", [7, 64])
+def test_backward_matches_oracle(gnntf, C):
+    coo, vals, shape = graphs.random_coo(400, 400, 5000, seed=31, weighted=True)
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=3, stream_id=2)      # dropped => asymmetric A_hat
+    ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=0.5, training=True, seed=3, stream=2)
+    rng = np.random.default_rng(C)
+    H = dev(rng.standard_normal((400, C)).astype(np.float32)).requires_grad_()
+    H0 = dev(rng.standard_normal((400, C)).astype(np.float32)).requires_grad_()
+    gout = rng.standard_normal((400, C)).astype(np.float32)
+    out = gnntf.ppr_step(adj, H, H0, 0.1)
+    out.backward(dev(gout))
+    wantH, wantH0 = orc.ppr_iteration_backward(ai, av, shape, gout, a=0.1)
+    np.testing.assert_allclose(H.grad.cpu().numpy(), wantH, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(H0.grad.cpu().numpy(), wantH0, rtol=1e-6)
+    X = dev(rng.standard_normal((400, C)).astype(np.float32)).requires_grad_()
+    gnntf.spmm(adj, X).backward(dev(gout))
+    np.testing.assert_allclose(X.grad.cpu().numpy(), wantH / np.float32(0.9), rtol=RTOL, atol=ATOL)
+
+
+# ---- golden fixtures: full models through the layer API ------------------------------------------------------
+def test_golden_cora_appnp_layer_api(gnntf, golden_dir):
+    from test_oracle_kat import load_cora
+    z, coo, vals, shape, X, weights = load_cora(golden_dir)
+    model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7)
+    dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
+    for layer, (W, b) in zip(dense, weights):
+        layer.W.data.copy_(dev(W)); layer.b.data.copy_(dev(b))
+    model.training_mode(False)
+    with torch.no_grad():
+        logits = model(model.features).cpu().numpy()
+    np.testing.assert_allclose(dense[-1].value.cpu().numpy(), z["H0"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(logits, z["logits32"], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(logits, z["logits64"], rtol=RTOL, atol=1e-6)
+    assert (logits.argmax(1) == z["argmax"]).all()           # identical labels on ALL 2708 rows
+    pred = model.predict(gnntf.NodeClassification(list(range(1708, 2708))))
+    assert pred.cpu().numpy().tolist() == z["argmax"][1708:].tolist()
+    assert model.graph.last_kernel() == "spmm_group8"
+
+
+def test_golden_arxiv_gcn_layer_api(gnntf, golden_dir):
+    z = np.load(os.path.join(golden_dir, "arxiv_mini_gcn.npz"))
+    coo, n = z["coo"].astype(np.int64), int(z["n"])
+    model = gnntf.GCN(gnntf.SparseCOO(coo, np.ones(len(coo), dtype=np.float32), (n, n)), z["X"].astype(np.float32), num_classes=40)
+    layers = model.layers()
+    layers[0].W.data.copy_(dev(z["W1"].astype(np.float32))); layers[0].b.data.copy_(dev(z["b1"].astype(np.float32)))
+    layers[1].W.data.copy_(dev(z["W2"].astype(np.float32))); layers[1].b.data.copy_(dev(z["b2"].astype(np.float32)))
+    model.training_mode(False)
+    with torch.no_grad():
+        out = model(model.features).cpu().numpy()
+    np.testing.assert_allclose(out, z["out32"], rtol=RTOL, atol=ATOL)
+    assert (out >= 0).all()
+
+
+def test_train_and_predict_end_to_end(gnntf):
+    """architecture.train()/predict() on the HIP path (README.md:26-68 usage), planted-partition graph."""
+    gnntf.set_seed(0)
+    rng = np.random.default_rng(0)
+    n, k = 1200, 4
+    labels = rng.integers(0, k, size=n)
+    src, dst = rng.integers(n, size=20000), rng.integers(n, size=20000)
+    keep = (labels[src] == labels[dst]) | (rng.random(20000) < 0.1)
+    import networkx as nx
+    G = nx.Graph()
+    G.add_nodes_from(range(n))
+    G.add_edges_from((int(u), int(v)) for u, v in zip(src[keep], dst[keep]) if u != v)
+    X = (np.eye(k)[labels] + rng.standard_normal((n, k)) * 2.0).astype(np.float32)
+    train, valid, test = list(range(0, 200)), list(range(200, 500)), list(range(500, n))
+    model = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=k)
+    model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
+                patience=30, epochs=150)
+    accuracy = gnntf.acc(model.predict(gnntf.NodeClassification(test)), labels[test])
+    mlp_like = (X[test].argmax(1) == labels[test]).mean()
+    assert accuracy > 0.9 and accuracy > mlp_like + 0.2       # propagation, not the features, does the work
+
+
+# ---- full-size properties (no oracle run at this size) ---------------------------------------------------------------
+def test_full_size_properties(gnntf):
+    """1M-node / 10M-entry RMAT at C=256: linearity and row-stochastic invariants of the device
+    path, which need no CPU reference."""
+    n = 1_000_000
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    src = torch.randint(0, n, (5_000_000,), device="cuda", generator=gen)
+    dst = (src + 1 + (torch.rand(5_000_000, device="cuda", generator=gen) ** 4 * (n - 1)).long()) % n
+    idx = torch.cat([torch.stack([src, dst], 1), torch.stack([dst, src], 1)])
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device="cuda"), (n, n)), device="cuda:0")
+    rowptr, colidx, _ = g.csr_arrays()
+    assert bool((rowptr[1:] >= rowptr[:-1]).all()) and int(rowptr[-1]) == g.nnz
+    bip = gnntf.normalize(g, "bipartite")
+    ones = torch.ones(n, 256, device="cuda")
+    rows = gnntf.spmm(bip, ones)
+    deg = (rowptr[1:] - rowptr[:-1]) > 0
+    assert torch.allclose(rows[deg], torch.ones_like(rows[deg]), rtol=1e-5)      # rows of D^-1 A sum to 1
+    assert float(rows[~deg].abs().sum()) == 0
+    sym = gnntf.normalize(g, "symmetric")
+    A = torch.rand(n, 256, device="cuda", generator=gen)
+    B = torch.rand(n, 256, device="cuda", generator=gen)
+    lhs = gnntf.spmm(sym, 2 * A + B)
+    rhs = 2 * gnntf.spmm(sym, A) + gnntf.spmm(sym, B)
+    assert torch.allclose(lhs, rhs, rtol=1e-4, atol=1e-5)                          # linearity
+    # <A x, y> == <x, A^T y>: the transposed kernel against the forward one
+    from gnntf.sparse import _launch
+    x, y = A[:, :64].contiguous(), B[:, :64].contiguous()
+    l = (gnntf.spmm(sym, x).double() * y.double()).sum()
+    r = (x.double() * _launch(sym, y, None, 1.0, 0.0, 0, transposed=True).double()).sum()
+    assert abs(float(l - r)) <= 1e-6 * abs(float(l))

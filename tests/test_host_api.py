@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's Layer / Layered / Trainable / Predictor protocol
+(reference gnntf/core/nn/layered.py, variables.py, trainable.py, layers.py,
+graph_predictor.py, graph_manipulation.py) -- everything that does not need the GPU."""
+import networkx as nx
+import numpy as np
+import pytest
+import torch
+
+import gnntf
+from oracle import gnntf_oracle as orc
+
+
+@pytest.fixture(autouse=True)
+def cpu_default():
+    gnntf.set_default_device("cpu")
+    yield
+    gnntf.set_default_device(None)
+
+
+class MLP(gnntf.Trainable):  # reference gnntf/core/nn/architectures/mlp.py:6-12
+    def __init__(self, features, num_classes, latent_dims=[16], dropout=0.5):
+        super().__init__(features)
+        self.add(gnntf.Dropout(dropout))
+        for d in latent_dims:
+            self.add(gnntf.Dense(d, activation=gnntf.relu, dropout=dropout))
+        self.add(gnntf.Dense(num_classes, regularize=False))
+
+
+def test_layer_protocol_and_shapes():
+    arch = gnntf.Layered((10, 6))
+    assert arch.top_shape() == (10, 6) and arch.is_training()
+    d1 = arch.add(gnntf.Dense(4, activation=gnntf.relu))
+    d2 = arch.add(gnntf.Dense())          # outputs default to the incoming width (layers.py:126-127)
+    assert d1.output_shape == (10, 4) and d2.output_shape == (10, 4) and arch.top_layer() is d2
+    assert len(d1.vars) == 2 and len(arch.vars()) == 4
+    assert [v.normalization for v in arch.vars()] == ["small", "zero", "small", "zero"]
+    arch.reset()
+    W = arch.vars()[0].var
+    assert W.shape == (6, 4) and float(W.detach().abs().max()) <= 0.5 + 1e-6      # U(+-1/sqrt(fan_out))
+    assert float(arch.vars()[1].var.abs().max()) == 0
+    out = arch(torch.ones(10, 6))
+    assert out.shape == (10, 4) and d1.value.shape == (10, 4) and (d1.value >= 0).all()
+    assert d2.value is out
+
+
+def test_layer_errors_match_reference_messages():
+    class NoBuild(gnntf.Layer):
+        pass
+
+    class NoShape(gnntf.Layer):
+        def __build__(self, arch):
+            return None
+
+    class NoForward(gnntf.Layer):
+        def __build__(self, arch):
+            return arch.top_shape()
+
+    arch = gnntf.Layered((3, 3))
+    with pytest.raises(Exception, match="Layer should implment a __build__ method"):
+        arch.add(NoBuild())
+    with pytest.raises(Exception, match="Layer __build__ should return an output shape"):
+        arch.add(NoShape())
+    arch.add(NoForward())
+    with pytest.raises(Exception, match="Layer should implement a __forward__ method"):
+        arch(torch.zeros(3, 3))
+    with pytest.raises(Exception, match="Invalid normalization type"):
+        gnntf.WrappedVariable((2, 2), normalization="nope").reset()
+    for method in ("predict", "loss", "evaluate"):
+        with pytest.raises(Exception, match="Predictors need to implement"):
+            getattr(gnntf.Predictor(), method)(None)
+
+
+def test_training_mode_quirk():
+    """Training mode starts True and only turns False when a `with` block exits (layered.py:9,37-42)."""
+    arch = gnntf.Layered((4, 4))
+    assert arch.is_training()
+    x = torch.ones(200, 50)
+    assert (arch.dropout(x, 0.5) == 0).any()
+    with arch as params:
+        assert params == [] and arch.is_training()
+    assert not arch.is_training()
+    assert arch.dropout(x, 0.5) is x
+    arch.training_mode(True)
+    assert arch.dropout(x, 0) is x and arch.is_training()
+
+
+def test_variable_sharing_and_init_schemes():
+    gen = gnntf.VariableGenerator()
+    a = gen.create_var((3, 3), "eye", shared_name="s")
+    b = gen.create_var((3, 3), "ones", shared_name="s")
+    assert a is b and len(gen.vars()) == 1
+    gen.create_var((4, 9), 0.25)
+    gen.create_var((4, 9), "bernouli", trainable=False, regularize=False)
+    gen.reset()
+    assert torch.equal(gen.vars()[0].var, torch.eye(3))
+    assert float(gen.vars()[1].var.abs().max()) <= 0.25
+    assert set(np.round(gen.vars()[2].numpy() * 3, 5).ravel().tolist()) <= {-1.0, 1.0}
+    assert gen.vars()[2].regularize == 0.0 and not gen.vars()[2].var.requires_grad
+    snap = gen.vars()[1].identity()
+    gen.vars()[1].assign(torch.zeros(4, 9))
+    assert float(gen.vars()[1].var.abs().sum()) == 0 and float(snap.abs().sum()) > 0
+    with pytest.raises(TypeError):
+        gen.create_var()          # the reference's APPNP(a=None) path raises the same way (filter.py:35)
+
+
+def test_node_classification_matches_oracle():
+    logits = torch.tensor(np.random.default_rng(0).standard_normal((30, 5)), dtype=torch.float32)
+    nodes, labels = [3, 7, 11, 29], np.array([0, 4, 2, 2])
+    task = gnntf.NodeClassification(nodes, labels)
+    assert task.predict(logits).tolist() == orc.node_predict(logits.numpy(), nodes).tolist()
+    assert float(task.loss(logits)) == pytest.approx(orc.node_loss(logits.numpy().astype(np.float64), nodes, labels), rel=1e-5)
+    assert task.evaluate(logits) == pytest.approx(orc.node_evaluate(logits.numpy(), nodes, labels))
+    with pytest.raises(Exception, match="Evaluation requires node labels"):
+        gnntf.NodeClassification(nodes).loss(logits)
+    assert gnntf.acc(task.predict(logits), labels) == pytest.approx(task.evaluate(logits))
+
+
+def test_graph2adj_matches_oracle():
+    G = nx.DiGraph()
+    G.add_nodes_from(["c", "a", "b", "z"])
+    G.add_edge("a", "b", weight=2.5)
+    G.add_edge("c", "a")
+    G.add_edge("b", "c", weight=0.5)
+    for directed in (False, True):
+        adj = gnntf.graph2adj(G, directed=directed)
+        weights = [d.get("weight", 1.0) for _, _, d in G.edges(data=True)]
+        idx, vals, shape = orc.graph2adj(list(G), list(G.edges()), weights, directed=directed)
+        assert adj.indices.numpy().tolist() == idx.tolist()
+        assert adj.values.numpy().tolist() == vals.tolist() and adj.dense_shape == shape
+    assert gnntf.graph2indices(G) == [[0, 1], [1, 2], [2, 0]]
+    back = gnntf.adj2graph(range(4), gnntf.graph2adj(G, directed=True))
+    assert sorted(back.edges()) == [(0, 1), (1, 2), (2, 0)]
+
+
+def test_trainable_loop_on_cpu_tensors():
+    """train(): reset, Adam, L2 on regularised vars, early stopping, best-weights restore, eval
+    mode afterwards, cached predict (trainable.py:41-103) -- on an MLP (no propagation layer)."""
+    gnntf.set_seed(0)
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((300, 8)).astype(np.float32)
+    labels = (X[:, 0] + X[:, 1] > 0).astype(np.int64)
+    model = MLP(X, 2, latent_dims=[16], dropout=0.1)
+    train, valid, test = list(range(0, 150)), list(range(150, 225)), list(range(225, 300))
+    model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
+                patience=20, epochs=200, learning_rate=0.05)
+    assert not model.is_training()
+    pred = model.predict(gnntf.NodeClassification(test))
+    assert gnntf.acc(pred, labels[test]) > 0.85
+    first = model._fast_predict
+    model.evaluate(gnntf.NodeClassification(test, labels[test]))
+    assert model._fast_predict is first       # memoised (trainable.py:26-29)
+    model.reset()
+    assert model._fast_predict is None
+
+
+def test_flow_layers():
+    arch = gnntf.Layered((5, 3))
+    a = arch.add(gnntf.Dense(3))
+    b = arch.add(gnntf.Activation("tanh"))
+    c = arch.add(gnntf.Resume(a))
+    t = arch.add(gnntf.Tradeoff([a, b]))
+    arch.reset()
+    out = arch(torch.ones(5, 3))
+    np.testing.assert_allclose(out.detach().numpy(), (0.5 * a.value + 0.5 * b.value).detach().numpy(), rtol=1e-6)
+    assert c.value is a.value and t.output_shape == (5, 3)
+    with pytest.raises(Exception, match="Mismatching trade-off dimentions"):
+        gnntf.Layered((5, 3), [gnntf.Dense(2)]).add(gnntf.Tradeoff([a, gnntf.Layered((5, 3)).add(gnntf.Dense(2))]))

@@ -1,0 +1,34 @@
+"""The C port of the oracle (oracle/propagate_ref.c, used as bench.py's cpu_baseline) agrees
+with the numpy restatement."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import graphs
+from oracle import gnntf_oracle as orc
+
+
+@pytest.fixture(scope="module")
+def cport():
+    import __graft_entry__ as ge
+    lib = ctypes.CDLL(ge.build_oracle())
+    lib.oracle_appnp_propagate.restype = ctypes.c_int
+    lib.oracle_appnp_propagate.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int64,
+                                                                                     ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("K,C", [(1, 7), (10, 16), (3, 64)])
+def test_c_port_matches_numpy_oracle(cport, K, C):
+    coo, vals, shape = graphs.rmat_symmetric_coo(500, 4000, seed=K)
+    rowptr, colidx, cvals = orc.coo_to_csr_coalesced(coo, vals, shape)
+    H0 = np.random.default_rng(C).uniform(-1, 1, size=(500, C)).astype(np.float32)
+    out = np.empty_like(H0)
+    work = np.empty_like(H0)
+    rc = cport.oracle_appnp_propagate(500, rowptr.ctypes.data, colidx.ctypes.data, cvals.ctypes.data, H0.ctypes.data,
+                                      0.1, K, C, out.ctypes.data, work.ctypes.data)
+    assert rc == 0
+    want = orc.appnp_propagate(coo, vals, shape, H0, a=0.1, iterations=K)
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-6)
+    assert cport.oracle_num_threads() >= 1
