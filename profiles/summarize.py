@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (gpurun_out/...) into the small files committed under profiles/.
+
+    python profiles/summarize.py <tag> <stats_dir> [<fetch_dir> <write_dir>] [--workload NAME]
+
+Writes profiles/<tag>_kernel_stats.csv (top kernels of `rocprofv3 --kernel-trace --stats`) and, when
+the two PMC passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_traffic.json (HBM-side
+bytes per propagation launch).  PMC correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE
+are in KiB; on gfx950 FETCH_SIZE counts 128-B requests of wide (16 B/lane) coalesced reads as 64 B, so
+the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def one(pattern):
+    files = glob.glob(pattern, recursive=True)
+    if not files:
+        raise SystemExit("no file matches " + pattern)
+    return files[0]
+
+
+def short(name):
+    m = re.search(r"(k_\w+(<[^>]*>)?)", name)
+    return m.group(1) if m else re.sub(r"\s+", " ", name)[:90]
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    workload = None
+    if "--workload" in sys.argv:
+        workload = sys.argv[sys.argv.index("--workload") + 1]
+        args = [a for a in args if a != workload]
+    tag, stats_dir = args[0], args[1]
+    rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "**", "*_kernel_stats.csv")))))
+    with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w") as f:
+        f.write("kernel,calls,total_ms,avg_ms,percent,min_ms,max_ms\n")
+        for r in rows[:14]:
+            f.write(f"\"{short(r['Name'])}\",{r['Calls']},{int(r['TotalDurationNs'])/1e6:.3f},{float(r['AverageNs'])/1e6:.4f},"
+                    f"{r['Percentage']},{int(r['MinNs'])/1e6:.4f},{int(r['MaxNs'])/1e6:.4f}\n")
+    if len(args) < 4:
+        return
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in args[2:4]:
+        for r in csv.DictReader(open(one(os.path.join(d, "**", "*_counter_collection.csv")))):
+            if "k_spmm" in r["Kernel_Name"]:
+                k = short(r["Kernel_Name"])
+                per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                per[k]["ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    total = 0.0
+    with open(os.path.join(HERE, f"{tag}_pmc.csv"), "w") as f:
+        f.write("kernel,dispatches,avg_ms,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB,hbm_read_bytes_corrected(x2),hbm_write_bytes,hbm_bytes\n")
+        for k, c in sorted(per.items()):
+            fetch = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)
+            write = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+            rd, wr = 2 * fetch * 1024, write * 1024
+            total += rd + wr
+            f.write(f"\"{k}\",{len(c['FETCH_SIZE'])},{sum(c['ms'])/len(c['ms']):.4f},{fetch:.1f},{write:.1f},{rd:.4e},{wr:.4e},{rd+wr:.4e}\n")
+    json.dump({"workload": workload, "hbm_bytes_per_launch": total,
+               "note": "sum over the kernels of one propagation iteration (spmm + long-row partial + reduce); "
+                       "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes; separate --pmc passes"},
+              open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
+    print("hbm bytes per launch: %.4e" % total)
+
+
+if __name__ == "__main__":
+    main()
