@@ -1,0 +1,310 @@
+"""1-D vertex-partitioned propagation over several MI355X (one process per GPU).
+
+The reference has no distributed code at all; this module is the
+multi-GPU form of the same hot path -- PPRIteration.__forward__ (reference
+gnntf/core/gnn/architectures/filter.py:17-22) over a normalised adjacency
+(gnntf/core/gnn/gnn.py:36-50) -- and must give the same logits as one GPU.
+
+Layout per rank r owning the global rows [lo, hi):
+  * the rows of A_hat with all their entries (a local CSR);
+  * a feature buffer  X = [ halo_low | local rows | halo_high ]  where halo_low / halo_high
+    are the remote rows this rank's entries reference with global id < lo / >= hi, each sorted
+    by global id.  The column remap global -> buffer position is therefore MONOTONIC, so the
+    order of a row's entries -- and with it the floating-point summation order of the kernel --
+    is the same as on one GPU;
+  * per peer q a send list (which of my rows q needs).
+Each iteration: pack the send rows (gnx_gather_rows) -> pairwise isend/irecv of the halo rows
+(RCCL group of point-to-point transfers: every xGMI link carries its own peer's rows; no ring)
+-> fused SpMM+mix over [X] writing the local part of the other ping-pong buffer.
+
+Column sums for the normalisation need one all-reduce of an N-vector at build time.
+The heavy lifting goes through a small backend object; the product backend is libgnx.so
+(NativeBackend).  Tests on CPU ranks (gloo) supply their own checker backend: this module
+never imports a CPU implementation.
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import _native as nat
+from . import sparse
+
+
+class NativeBackend:
+    """libgnx.so through ctypes; every tensor lives on this rank's GPU."""
+
+    def graph_from_coo(self, idx, vals, shape):
+        return sparse.DeviceGraph(sparse.SparseCOO(idx, vals, shape), device=idx.device)
+
+    def graph_from_csr(self, rowptr, colidx, vals, shape):
+        return sparse.DeviceGraph(csr=(rowptr, colidx, vals, shape))
+
+    def csr_arrays(self, graph):
+        return graph.csr_arrays()
+
+    def colsum(self, graph):
+        out = torch.empty(graph.n_cols, dtype=torch.float32, device=graph.device)
+        with torch.cuda.device(graph.device):
+            nat.check(nat.lib().gnx_graph_colsum(graph.handle, 0.0, 0, 0, nat.ptr(out), nat.current_stream()))
+        return out
+
+    def degree_scale(self, deg, normalized="symmetric"):
+        with torch.cuda.device(deg.device):
+            nat.check(nat.lib().gnx_degree_scale(nat.ptr(deg), deg.numel(), nat.NORM[normalized], 0, nat.current_stream()))
+        return deg
+
+    def scale_values(self, graph, row_scale, col_scale):
+        out = torch.empty(graph.nnz, dtype=torch.float32, device=graph.device)
+        row_scale = row_scale.contiguous() if row_scale is not None else None
+        with torch.cuda.device(graph.device):
+            nat.check(nat.lib().gnx_graph_scale_values(graph.handle, 0.0, 0, 0, nat.ptr(row_scale), nat.ptr(col_scale),
+                                                       nat.ptr(out), nat.current_stream()))
+        return out
+
+    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out):
+        sparse._launch(sparse.Adjacency(graph, vals), X, H0, beta, alpha, nat.ACT_NONE, out=out)
+
+    def gather_rows(self, X, idx):
+        return sparse.gather_rows(X, idx)
+
+
+def _staged(t, group):
+    """gloo cannot move device tensors point-to-point: such groups (tests, rehearsals of several
+    ranks on one card) stage through host memory.  RCCL groups never take this path."""
+    return t is not None and t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, group=None, op=dist.ReduceOp.SUM):
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def _all_gather_vec(t, group=None):
+    world = dist.get_world_size(group)
+    src = t.cpu() if _staged(t, group) else t
+    table = [torch.zeros_like(src) for _ in range(world)]
+    dist.all_gather(table, src, group=group)
+    return [x.to(t.device) for x in table]
+
+
+def _exchange(send_chunks, recv_chunks, group=None):
+    """Pairwise exchange: send_chunks[q] goes to rank q, recv_chunks[q] is filled from rank q.
+    One batch of point-to-point operations (NCCL/RCCL: a single group call)."""
+    rank = dist.get_rank(group)
+    if any(_staged(t, group) for t in list(send_chunks) + list(recv_chunks)):
+        host_recv = [None if t is None else torch.empty(t.shape, dtype=t.dtype) for t in recv_chunks]
+        _exchange([None if t is None else t.cpu() for t in send_chunks], host_recv, group)
+        for q, (d, h) in enumerate(zip(recv_chunks, host_recv)):
+            if q != rank and d is not None and d.numel() > 0:
+                d.copy_(h)
+        return
+    ops = []
+    for q, t in enumerate(recv_chunks):
+        if q != rank and t is not None and t.numel() > 0:
+            ops.append(dist.P2POp(dist.irecv, t, q, group))
+    for q, t in enumerate(send_chunks):
+        if q != rank and t is not None and t.numel() > 0:
+            ops.append(dist.P2POp(dist.isend, t, q, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def uniform_bounds(n_global, world):
+    return [r * n_global // world for r in range(world + 1)]
+
+
+class ShardState:
+    """Ping-pong feature buffers of one propagation."""
+
+    def __init__(self, bufs, H0):
+        self.bufs, self.H0, self.cur = bufs, H0, 0
+
+
+class ShardedGraph:
+    """This rank's shard of a symmetrically normalised, vertex-partitioned square graph."""
+
+    def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric"):
+        """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this
+        rank owns (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.
+        Collective: every rank of ``group`` must call it."""
+        self.backend = backend if backend is not None else NativeBackend()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        be = self.backend
+        dev = idx_global.device
+        self.device = dev
+        self.bounds = [int(b) for b in bounds]
+        lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        N = self.bounds[-1]
+        self.lo, self.hi, self.n_global, self.n_local = lo, hi, N, hi - lo
+        if idx_global.numel() and (int(idx_global[:, 0].min()) < lo or int(idx_global[:, 0].max()) >= hi):
+            raise Exception("ShardedGraph: an entry's row is outside this rank's range [%d, %d)" % (lo, hi))
+
+        # local rows x global columns: coalesce, then normalise with GLOBAL column sums (gnn.py:41-42)
+        local_idx = idx_global.clone()
+        local_idx[:, 0] -= lo
+        g0 = be.graph_from_coo(local_idx, vals, (self.n_local, N))
+        rowptr, colidx, raw = be.csr_arrays(g0)
+        if normalized == "symmetric":
+            deg = be.colsum(g0)
+            _all_reduce(deg, group)
+            D = be.degree_scale(deg, "symmetric")
+            nvals = be.scale_values(g0, D[lo:hi], D)
+        elif normalized == "none":
+            nvals = raw
+        else:
+            raise Exception("Invalid matrix normalization")
+        self.nnz_local = int(colidx.numel())
+        t = torch.tensor([self.nnz_local], dtype=torch.int64, device=dev)
+        _all_reduce(t, group)
+        self.nnz_global = int(t.item())
+
+        # halo plan: distinct remote columns, sorted by global id (=> grouped by owner)
+        col = colidx.to(torch.int64)
+        remote = (col < lo) | (col >= hi)
+        halo = torch.unique(col[remote])
+        self.halo_ids = halo                     # global ids of the halo rows: [low part | high part], ascending
+        n_low = int((halo < lo).sum())
+        self.n_low, self.n_high = n_low, int(halo.numel()) - n_low
+        pos = torch.searchsorted(halo, col)
+        new_col = torch.where(col < lo, pos, torch.where(col >= hi, pos + self.n_local, col - lo + n_low))
+        self.n_buf = self.n_low + self.n_local + self.n_high
+        self.graph = be.graph_from_csr(rowptr, new_col.to(torch.int32), nvals, (self.n_local, self.n_buf))
+        self.vals = None   # values live in the handle (raw values of the remapped CSR are already normalised)
+        del g0
+
+        # who owns which halo row; what every peer needs from me
+        bnd = torch.tensor(self.bounds[1:], dtype=torch.int64, device=dev)
+        owner = torch.bucketize(halo, bnd, right=True)
+        recv_counts = torch.bincount(owner, minlength=self.world).to(torch.int64)
+        table = _all_gather_vec(recv_counts, group)
+        self.recv_counts = [int(c) for c in recv_counts.tolist()]
+        self.send_counts = [int(table[q][self.rank]) for q in range(self.world)]
+        roff = [0]
+        for c in self.recv_counts:
+            roff.append(roff[-1] + c)
+        want = [halo[roff[q]:roff[q + 1]].contiguous() for q in range(self.world)]      # ids I ask of q
+        asked = [torch.empty(self.send_counts[q], dtype=torch.int64, device=dev) for q in range(self.world)]
+        _exchange(want, asked, group)
+        self.send_idx = (torch.cat(asked) - lo) if sum(self.send_counts) else torch.empty(0, dtype=torch.int64, device=dev)
+        if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
+            raise Exception("ShardedGraph: a peer asked for a row this rank does not own")
+        # where each peer's rows land in the buffer: low part for q < rank, high part for q > rank
+        self.recv_slices = []
+        for q in range(self.world):
+            start = roff[q] if q < self.rank else roff[q] + self.n_local
+            self.recv_slices.append((start, start + self.recv_counts[q]))
+        soff = [0]
+        for c in self.send_counts:
+            soff.append(soff[-1] + c)
+        self.send_slices = [(soff[q], soff[q + 1]) for q in range(self.world)]
+
+    # ---- propagation -----------------------------------------------------------------------------
+    def local_view(self, buf):
+        return buf[self.n_low:self.n_low + self.n_local]
+
+    def make_state(self, H0):
+        """Allocates the two [halo_low | local | halo_high] buffers for features of H0's width."""
+        H0 = H0.to(torch.float32).contiguous()
+        if H0.shape[0] != self.n_local:
+            raise Exception("make_state: H0 must hold this rank's %d rows" % self.n_local)
+        bufs = [torch.zeros((self.n_buf, H0.shape[1]), dtype=torch.float32, device=H0.device) for _ in range(2)]
+        return ShardState(bufs, H0)
+
+    def exchange_halo(self, buf):
+        """Fills the halo rows of ``buf`` with the owners' current local rows."""
+        local = self.local_view(buf)
+        packed = self.backend.gather_rows(local, self.send_idx) if self.send_idx.numel() else None
+        sends = [packed[a:b] if packed is not None and b > a else None for a, b in self.send_slices]
+        recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
+        _exchange(sends, recvs, self.group)
+
+    def step(self, state: ShardState, a: float):
+        """One PPRIteration over the shard: halo exchange + fused SpMM/mix."""
+        cur, nxt = state.bufs[state.cur], state.bufs[1 - state.cur]
+        self.exchange_halo(cur)
+        self.backend.spmm_mix(self.graph, None, cur, state.H0, 1.0 - a, a, self.local_view(nxt))
+        state.cur = 1 - state.cur
+
+    def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10):
+        """H <- H0, then K iterations; returns this rank's rows of the result (a view)."""
+        state.cur = 0
+        self.local_view(state.bufs[0]).copy_(state.H0)
+        for _ in range(iterations):
+            self.step(state, a)
+        return self.local_view(state.bufs[state.cur])
+
+    def halo_stats(self):
+        t = torch.tensor([self.n_low + self.n_high, int(self.send_idx.numel()), self.n_local], dtype=torch.int64, device=self.device)
+        _all_reduce(t, self.group, dist.ReduceOp.MAX)
+        return {"max_halo_rows": int(t[0]), "max_send_rows": int(t[1]), "max_local_rows": int(t[2])}
+
+
+# ---- synthetic sharded R-MAT (bench.py, N > 1) ------------------------------------------------------------
+def _rmat_pairs(scale, m, gen, device, a=0.57, b=0.19, c=0.19):
+    src = torch.zeros(m, dtype=torch.int64, device=device)
+    dst = torch.zeros(m, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        r = torch.rand(m, device=device, generator=gen)
+        src = src * 2 + (r >= a + b).long()
+        dst = dst * 2 + (((r >= a) & (r < a + b)) | (r >= a + b + c)).long()
+    return src, dst
+
+
+def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=None, group=None):
+    """Weak-scaling workload: a global R-MAT graph with nodes_per_rank * P vertices and about
+    entries_per_rank * P stored (symmetrised, de-duplicated) entries.  Every rank draws its share
+    of undirected edges, applies the same global vertex permutation, routes both directions of
+    every edge to the owner of its row, and builds its shard."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    N = nodes_per_rank * world
+    t0 = time.time()
+    gen = torch.Generator(device=device).manual_seed(seed * 1000003 + rank)
+    scale = max(1, (N - 1).bit_length())
+    m = entries_per_rank // 2
+    s, d = _rmat_pairs(scale, int(m * 1.012), gen, device)     # ~1 % are lost to self loops / duplicates
+    s, d = s % N, d % N
+    keep = s != d
+    s, d = s[keep], d[keep]
+    keys = torch.unique(torch.minimum(s, d) * N + torch.maximum(s, d))
+    del s, d, keep
+    pgen = torch.Generator(device=device).manual_seed(3)
+    perm = torch.randperm(N, device=device, generator=pgen)          # identical on every rank
+    u, v = perm[keys // N], perm[keys % N]
+    del keys, perm
+    rows, cols = torch.cat([u, v]), torch.cat([v, u])
+    del u, v
+    owner = rows // nodes_per_rank
+    order = torch.argsort(owner)
+    packed = (rows * N + cols)[order]
+    counts = torch.bincount(owner, minlength=world).to(torch.int64)
+    del rows, cols, owner, order
+    table = _all_gather_vec(counts, group)
+    off = [0]
+    for c in counts.tolist():
+        off.append(off[-1] + int(c))
+    sends = [packed[off[q]:off[q + 1]] for q in range(world)]
+    recvs = [torch.empty(int(table[q][rank]), dtype=torch.int64, device=device) for q in range(world)]
+    recvs[rank] = sends[rank]
+    _exchange(sends, recvs, group)
+    mine = torch.unique(torch.cat(recvs))                             # de-duplicate across ranks
+    del packed, sends, recvs
+    idx = torch.stack([mine // N, mine % N], dim=1)
+    vals = torch.ones(idx.shape[0], dtype=torch.float32, device=device)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    sg = ShardedGraph(idx, vals, uniform_bounds(N, world), backend=backend, group=group)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2))

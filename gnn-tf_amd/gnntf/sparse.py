@@ -151,7 +151,7 @@ def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False):
+def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None):
     g = adj.graph
     nat.require_cuda(X, H0)
     X = _as_f32_rows(X)
@@ -160,7 +160,10 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False):
     if X.shape[0] != rows_in:
         raise Exception(f"spmm: features have {X.shape[0]} rows, adjacency expects {rows_in}")
     C = X.shape[1]
-    out = torch.empty((rows_out, C), dtype=torch.float32, device=X.device)
+    if out is None:
+        out = torch.empty((rows_out, C), dtype=torch.float32, device=X.device)
+    elif (tuple(out.shape) != (rows_out, C) or out.dtype != torch.float32 or out.stride(1) != 1 or not out.is_cuda):
+        raise Exception("spmm: bad output buffer")
     if H0 is not None:
         H0 = _as_f32_rows(H0)
         if tuple(H0.shape) != (rows_out, C):
