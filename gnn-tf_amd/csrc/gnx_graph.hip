@@ -120,6 +120,17 @@ __global__ void k_flag_long(const int64_t *__restrict__ rowptr, int64_t n_rows, 
     cnt[r] = lg ? (d + LONG_CHUNK - 1) / LONG_CHUNK : 0;
 }
 
+// sort key of the degree-binned row order: 255 - min(entries, 255), so an ascending stable sort
+// puts the heaviest rows first and keeps ascending row ids inside a bin
+__global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows, uint8_t *__restrict__ keys,
+                             int32_t *__restrict__ ids) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t d = rowptr[r + 1] - rowptr[r];
+    keys[r] = (uint8_t)(255 - (d < 255 ? d : 255));
+    ids[r] = (int32_t)r;
+}
+
 __global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, const int32_t *__restrict__ pos,
                             const int64_t *__restrict__ cpos, int32_t *__restrict__ long_rows,
                             int64_t *__restrict__ long_chunk_ptr, int32_t *__restrict__ chunk_long) {
@@ -158,12 +169,28 @@ void free_csr(Csr &m) {
     if (m.long_rows) (void)hipFree(m.long_rows);
     if (m.long_chunk_ptr) (void)hipFree(m.long_chunk_ptr);
     if (m.chunk_long) (void)hipFree(m.chunk_long);
+    if (m.row_order) (void)hipFree(m.row_order);
     m = Csr();
 }
 
 int build_long_plan(Csr &m, hipStream_t s) {
     m.n_long = 0; m.n_chunks = 0;
-    if (m.n_rows == 0 || m.nnz == 0) return GNX_OK;
+    if (m.n_rows == 0) return GNX_OK;
+    {   // degree-binned row order
+        DevBuf k0, k1, ids, t;
+        GNX_HIP(k0.alloc(m.n_rows)); GNX_HIP(k1.alloc(m.n_rows)); GNX_HIP(ids.alloc(m.n_rows * sizeof(int32_t)));
+        GNX_HIP(hipMalloc((void **)&m.row_order, m.n_rows * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, k0.as<uint8_t>(),
+                           ids.as<int32_t>());
+        size_t tb = 0;
+        GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint8_t>(), k1.as<uint8_t>(), ids.as<int32_t>(), m.row_order,
+                                          (size_t)m.n_rows, 0u, 8u, s));
+        GNX_HIP(t.alloc(tb));
+        GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint8_t>(), k1.as<uint8_t>(), ids.as<int32_t>(), m.row_order,
+                                          (size_t)m.n_rows, 0u, 8u, s));
+        GNX_HIP(hipStreamSynchronize(s));
+    }
+    if (m.nnz == 0) return GNX_OK;
     DevBuf flag, cnt, pos, cpos, tmp;
     GNX_HIP(flag.alloc(m.n_rows * sizeof(int32_t)));
     GNX_HIP(cnt.alloc(m.n_rows * sizeof(int64_t)));
@@ -222,6 +249,8 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
     if (t.nnz == 0) {
         GNX_HIP(hipMemsetAsync(t.rowptr, 0, (t.n_rows + 1) * sizeof(int64_t), s));
         GNX_HIP(hipStreamSynchronize(s));
+        int rc0 = build_long_plan(t, s);
+        if (rc0 != GNX_OK) return rc0;
         g->has_t = true;
         return GNX_OK;
     }
@@ -302,6 +331,8 @@ int gnx_graph_create_coo(int64_t n_rows, int64_t n_cols, int64_t nnz, const int6
         GNX_HIP(hipMalloc((void **)&g->raw_vals, 16));
         GNX_HIP(hipMalloc((void **)&g->rowidx, 16));
         GNX_HIP(hipStreamSynchronize(s));
+        int rc0 = finish_graph(g, s);
+        if (rc0 != GNX_OK) return rc0;
         guard.g = nullptr; *out = g;
         return GNX_OK;
     }

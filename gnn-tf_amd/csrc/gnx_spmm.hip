@@ -150,8 +150,9 @@ template <int VEC, int G, int U>
 __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
-    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
-    if (row >= p.n_rows) return;
+    const int64_t slot = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+    if (slot >= p.n_rows) return;
+    const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;   // degree-binned: the rows of one wave have similar lengths
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > LONG_ROW) return;
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
@@ -161,28 +162,25 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        int64_t e = beg;
-        for (; e + U <= end; e += U) {
+        for (int64_t e = beg; e < end; e += U) {   // U entries in flight per lane, ragged tail predicated
             float x[U][VEC];
             float w[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int j = p.colidx[e + u];
-                w[u] = p.vals[e + u];
-                vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                if (e + u < end) {
+                    const int j = p.colidx[e + u];
+                    w[u] = p.vals[e + u];
+                    vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                } else {
+                    w[u] = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
-        }
-        for (; e < end; ++e) {
-            float x[VEC];
-            const int j = p.colidx[e];
-            const float w = p.vals[e];
-            vload<VEC>(x, Xc + (int64_t)j * p.ldx);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[v], acc[v]);
         }
         epilogue_store<VEC>(p, row, c, active, acc);
     }
@@ -309,6 +307,7 @@ namespace gnx {
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
+    p.row_order = m.row_order;
     p.n_long = m.n_long; p.n_chunks = m.n_chunks;
     p.partial = nullptr;
     if (m.n_rows == 0) return GNX_OK;
