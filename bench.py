@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--feats", type=int, default=256)
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--alpha", type=float, default=0.1)
+    ap.add_argument("--grid", type=str, default="", help="PVxPF process grid (vertex blocks x feature slices); default: chosen by gnntf.sharded.choose_grid")
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     return ap.parse_args()
@@ -170,10 +171,15 @@ def main():
         halo = None
     else:
         from gnntf import sharded
-        sg, prep = sharded.build_rmat_shard(args.nodes, args.entries, seed=1, device=device)
+        if args.grid:
+            grid = tuple(int(x) for x in args.grid.split("x"))
+        else:
+            grid = sharded.choose_grid(world, C)
+        sg, prep, (gv, gf, pv, pf) = sharded.build_rmat_shard(args.nodes, args.entries, seed=1, device=device, grid=grid)
         n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
+        C_local = C // pf                                                       # this rank's feature slice
         gen = torch.Generator(device=device).manual_seed(2 + rank)
-        H0 = torch.rand(n_local, C, device=device, generator=gen) * 2 - 1
+        H0 = torch.rand(n_local, C_local, device=device, generator=gen) * 2 - 1
         state = sg.make_state(H0)
 
         def step():
@@ -205,7 +211,7 @@ def main():
     if rank == 0:
         edges = nnz_global * K * args.steps
         launch_s = (sum(step_ms) / len(step_ms)) / 1e3 / K          # one fused SpMM+mix launch (+ its long-row tail)
-        b_alg = alg_bytes_per_iteration(n_local, nnz_local, C)
+        b_alg = alg_bytes_per_iteration(n_local, nnz_local, C_local if sharded_path else C)
         achieved = b_alg / launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -219,7 +225,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rmat_n{args.nodes}_nnz{args.entries}_C{C}_appnp_K{K}" + ("" if world == 1 else f"_per_gpu_x{world}"),
                        "nodes_per_gpu": n_local, "stored_entries_per_gpu": nnz_local, "stored_entries_total": nnz_global,
-                       "features": C, "iterations": K, "alpha": a, "partition": f"1d_vertex_x{world}" if sharded_path else "none",
+                       "features": C, "iterations": K, "alpha": a, "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (sg.graph.last_kernel() if sharded_path else g.last_kernel())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "alg_bytes_per_launch": b_alg, "launch_ms": launch_s * 1e3,

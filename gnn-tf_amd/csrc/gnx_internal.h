@@ -104,8 +104,10 @@ struct SpmmArgs {
     const int32_t *row_order;
     float *partial;
     int64_t n_long, n_chunks;
+    int tune;
 };
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);
+extern int tune_override;
 
 }  // namespace gnx

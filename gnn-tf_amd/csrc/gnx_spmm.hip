@@ -17,6 +17,8 @@
 //   * power-law rows: a row with more than LONG_ROW entries is cut into LONG_CHUNK-entry
 //     chunks summed by separate waves into a partial slab, then added in chunk order by a
 //     second kernel (fixed order: results are bitwise reproducible, no float atomics).
+#include <stdlib.h>
+
 #include "gnx_internal.h"
 
 using namespace gnx;
@@ -42,6 +44,28 @@ __device__ __forceinline__ void vstore(float *__restrict__ p, const float (&x)[V
     *reinterpret_cast<T *>(p) = v;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int VEC> struct NatT;
+template <> struct NatT<1> { using type = float; };
+template <> struct NatT<2> { using type = f32x2; };
+template <> struct NatT<4> { using type = f32x4; };
+
+// streaming (touched once per launch) data: non-temporal so it does not evict gathered rows
+template <int VEC>
+__device__ __forceinline__ void vload_nt(float (&x)[VEC], const float *__restrict__ p) {
+    using T = typename NatT<VEC>::type;
+    const T v = __builtin_nontemporal_load(reinterpret_cast<const T *>(p));
+    __builtin_memcpy(x, &v, sizeof(T));
+}
+template <int VEC>
+__device__ __forceinline__ void vstore_nt(float *__restrict__ p, const float (&x)[VEC]) {
+    using T = typename NatT<VEC>::type;
+    T v;
+    __builtin_memcpy(&v, x, sizeof(T));
+    __builtin_nontemporal_store(v, reinterpret_cast<T *>(p));
+}
+
 __device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -52,14 +76,19 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 template <int VEC, int U>
 __device__ __forceinline__ void wave_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
                                                 const float *__restrict__ X, int64_t ldx, int64_t beg, int64_t end,
-                                                int c, int lane, float (&acc)[VEC]) {
+                                                int c, int lane, float (&acc)[VEC], bool nt_index = false) {
     for (int64_t base = beg; base < end; base += 64) {
         const int n = (int)((end - base) < 64 ? (end - base) : 64);
         int mycol = 0;
         float myval = 0.f;
         if (lane < n) {
-            mycol = colidx[base + lane];
-            myval = vals[base + lane];
+            if (nt_index) {
+                mycol = __builtin_nontemporal_load(colidx + base + lane);
+                myval = __builtin_nontemporal_load(vals + base + lane);
+            } else {
+                mycol = colidx[base + lane];
+                myval = vals[base + lane];
+            }
         }
         int i = 0;
         for (; i + U <= n; i += U) {
@@ -99,7 +128,8 @@ __device__ __forceinline__ void wave_accumulate(const int32_t *__restrict__ coli
 
 // filter.py:20-22: out = act(acc*beta + h0*alpha), with the add_eye diagonal folded in first.
 template <int VEC>
-__device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, int c, bool active, float (&acc)[VEC]) {
+__device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, int c, bool active, float (&acc)[VEC],
+                                               bool nt = false) {
     if (!active) return;
     if (p.diag) {
         const float d = p.diag[row];
@@ -111,7 +141,8 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
     float o[VEC];
     if (p.H0) {
         float h0[VEC];
-        vload<VEC>(h0, p.H0 + row * p.ldh0 + c);
+        if (nt) vload_nt<VEC>(h0, p.H0 + row * p.ldh0 + c);
+        else vload<VEC>(h0, p.H0 + row * p.ldh0 + c);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = acc[v] * p.beta + h0[v] * p.alpha;
     } else {
@@ -122,16 +153,19 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = fmaxf(o[v], 0.f);
     }
-    vstore<VEC>(p.out + row * p.ldo + c, o);
+    if (nt) vstore_nt<VEC>(p.out + row * p.ldo + c, o);
+    else vstore<VEC>(p.out + row * p.ldo + c, o);
 }
 
 // ---- wide path: one wave per row -----------------------------------------------------------
-template <int VEC, int U>
-__global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs p) {
+// tune bits (GNX_TUNE, experiments): 1 = degree-binned row order, 2 = non-temporal H0/out, 4 = non-temporal col/val
+template <int VEC, int U, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_spmm_wave(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t row = (int64_t)blockIdx.x * 4 + wib;
-    if (row >= p.n_rows) return;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + wib;
+    if (slot >= p.n_rows) return;
+    const int64_t row = (p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > LONG_ROW) return;  // k_spmm_long_* take it
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
@@ -140,13 +174,14 @@ __global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs p) {
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        wave_accumulate<VEC, U>(p.colidx, p.vals, p.X, p.ldx, beg, end, active ? c : 0, lane, acc);
-        epilogue_store<VEC>(p, row, c, active, acc);
+        wave_accumulate<VEC, U>(p.colidx, p.vals, p.X, p.ldx, beg, end, active ? c : 0, lane, acc, (p.tune & 4) != 0);
+        epilogue_store<VEC>(p, row, c, active, acc, (p.tune & 2) != 0);
     }
 }
 
 // ---- narrow path: G lanes per row, 256/G rows per block ---------------------------------------
-template <int VEC, int G, int U>
+// PIPE: the (col, val) pairs of batch b+1 are fetched while the gathers of batch b are in flight.
+template <int VEC, int G, int U, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
@@ -162,25 +197,59 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        for (int64_t e = beg; e < end; e += U) {   // U entries in flight per lane, ragged tail predicated
-            float x[U][VEC];
-            float w[U];
+        if (PIPE) {
+            int jn[U];
+            float wn[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (e + u < end) {
-                    const int j = p.colidx[e + u];
-                    w[u] = p.vals[e + u];
-                    vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
-                } else {
-                    w[u] = 0.f;
-#pragma unroll
-                    for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
-                }
+                const bool ok = beg + u < end;
+                jn[u] = ok ? p.colidx[beg + u] : -1;
+                wn[u] = ok ? p.vals[beg + u] : 0.f;
             }
+            for (int64_t e = beg; e < end; e += U) {
+                float x[U][VEC];
+                float w[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+                for (int u = 0; u < U; ++u) {          // gathers of this batch
+                    w[u] = wn[u];
+                    if (jn[u] >= 0) vload<VEC>(x[u], Xc + (int64_t)jn[u] * p.ldx);
+                    else {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+                        for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {          // indices of the next batch, behind the gathers
+                    const bool ok = e + U + u < end;
+                    jn[u] = ok ? p.colidx[e + U + u] : -1;
+                    wn[u] = ok ? p.vals[e + U + u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+            }
+        } else {
+            for (int64_t e = beg; e < end; e += U) {   // U entries in flight per lane, ragged tail predicated
+                float x[U][VEC];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e + u < end) {
+                        const int j = p.colidx[e + u];
+                        w[u] = p.vals[e + u];
+                        vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                    } else {
+                        w[u] = 0.f;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+            }
         }
         epilogue_store<VEC>(p, row, c, active, acc);
     }
@@ -276,12 +345,27 @@ int pick_vec(const SpmmArgs &p) {
 template <int VEC>
 const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;  // lanes needed to cover one row
-    if (lanes > 32) { GNX_LAUNCH((k_spmm_wave<VEC, 8>), blocks_for(p.n_rows, 4), p); return "spmm_wave"; }
-    if (lanes > 16) { GNX_LAUNCH((k_spmm_group<VEC, 32, 4>), blocks_for(p.n_rows, 8), p); return "spmm_group32"; }
-    if (lanes > 8)  { GNX_LAUNCH((k_spmm_group<VEC, 16, 4>), blocks_for(p.n_rows, 16), p); return "spmm_group16"; }
-    if (lanes > 4)  { GNX_LAUNCH((k_spmm_group<VEC, 8, 4>), blocks_for(p.n_rows, 32), p); return "spmm_group8"; }
-    GNX_LAUNCH((k_spmm_group<VEC, 4, 4>), blocks_for(p.n_rows, 64), p);
+    if (lanes > 32) {
+        // measured: U = 8 rows in flight is the plateau (U=4 +0.7 %, U=16 +17 %, forcing 8 waves/SIMD +14 %,
+        // degree-ordered rows +9 %, non-temporal H0/out/index loads +-0 %)
+        GNX_LAUNCH((k_spmm_wave<VEC, 8, 1>), blocks_for(p.n_rows, 4), p);
+        return "spmm_wave";
+    }
+    // measured (tools/tune_spmm.py, RMAT 10M/100M): prefetching the next (col, val) batch behind the
+    // gathers pays for G <= 8 (C <= 32: -8..-12 %) and not for the wider groups
+    const int gsel = (p.tune >> 8) & 3;          // experiments: 1 = force plain, 2 = force pipelined
+#define GNX_GROUP(G, RPB_, PIPE_DEFAULT)                                                              \
+    do {                                                                                              \
+        const bool pipe = gsel == 2 || (gsel == 0 && PIPE_DEFAULT);                                   \
+        if (pipe) GNX_LAUNCH((k_spmm_group<VEC, G, 4, true>), blocks_for(p.n_rows, RPB_), p);         \
+        else      GNX_LAUNCH((k_spmm_group<VEC, G, 4, false>), blocks_for(p.n_rows, RPB_), p);        \
+    } while (0)
+    if (lanes > 16) { GNX_GROUP(32, 8, false); return "spmm_group32"; }
+    if (lanes > 8)  { GNX_GROUP(16, 16, false); return "spmm_group16"; }
+    if (lanes > 4)  { GNX_GROUP(8, 32, true); return "spmm_group8"; }
+    GNX_GROUP(4, 64, true);
     return "spmm_group4";
+#undef GNX_GROUP
 }
 
 template <int VEC>
@@ -304,10 +388,16 @@ int check_common(const char *fn, gnx_graph *g, const float *X, int64_t ldx, int6
 
 namespace gnx {
 
+int tune_override = -1;   // set through gnx_debug_set_tune (experiments only)
+
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
+    {
+        static const int tune = [] { const char *e = getenv("GNX_TUNE"); return e ? atoi(e) : 0; }();
+        p.tune = tune_override >= 0 ? tune_override : tune;
+    }
     p.n_long = m.n_long; p.n_chunks = m.n_chunks;
     p.partial = nullptr;
     if (m.n_rows == 0) return GNX_OK;
@@ -329,6 +419,9 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
 }  // namespace gnx
 
 extern "C" {
+
+// not part of include/gnx.h: lets tools/tune_spmm.py flip kernel variants inside one process
+int gnx_debug_set_tune(int t) { tune_override = t; return 0; }
 
 int gnx_spmm(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx, int64_t C,
              const float *d_H0, int64_t ldh0, float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream) {

@@ -1,4 +1,8 @@
-"""1-D vertex-partitioned propagation over several MI355X (one process per GPU).
+"""Multi-GPU propagation (one process per GPU): a pv x pf grid of vertex blocks x feature slices.
+
+Feature columns propagate independently (the step acts on every column of H alike), so slicing the
+columns over ranks needs no exchange at all; vertex blocks need the halo exchange described below.
+choose_grid() takes feature slices while they stay >= 32 columns wide and vertex blocks for the rest.
 
 The reference has no distributed code at all; this module is the
 multi-GPU form of the same hot path -- PPRIteration.__forward__ (reference
@@ -71,51 +75,94 @@ class NativeBackend:
         return sparse.gather_rows(X, idx)
 
 
-def _staged(t, group):
-    """gloo cannot move device tensors point-to-point: such groups (tests, rehearsals of several
-    ranks on one card) stage through host memory.  RCCL groups never take this path."""
-    return t is not None and t.is_cuda and dist.get_backend(group) == "gloo"
+class Comm:
+    """The ranks that share one vertex partition (a torch.distributed group, or a single process).
+    A one-rank Comm never touches torch.distributed, so a feature-sliced grid with one vertex block
+    per slice has no data-path communication at all."""
+
+    def __init__(self, group=None, solo=False):
+        self.group, self.solo = group, solo
+        self.rank = 0 if solo else dist.get_rank(group)
+        self.size = 1 if solo else dist.get_world_size(group)
+
+    def _staged(self, t):
+        # gloo cannot move device tensors point-to-point: such groups (tests, rehearsals of several
+        # ranks on one card) stage through host memory.  RCCL groups never take this path.
+        return t is not None and t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def all_reduce(self, t, op=None):
+        if self.size == 1:
+            return t
+        op = dist.ReduceOp.SUM if op is None else op
+        if self._staged(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+    def all_gather_vec(self, t):
+        if self.size == 1:
+            return [t]
+        src = t.cpu() if self._staged(t) else t
+        table = [torch.zeros_like(src) for _ in range(self.size)]
+        dist.all_gather(table, src, group=self.group)
+        return [x.to(t.device) for x in table]
+
+    def exchange(self, send_chunks, recv_chunks):
+        """Pairwise exchange: send_chunks[q] goes to group rank q, recv_chunks[q] is filled from it.
+        One batch of point-to-point operations (NCCL/RCCL: a single group call, every peer pair on
+        its own xGMI link)."""
+        if self.size == 1:
+            return
+        if any(self._staged(t) for t in list(send_chunks) + list(recv_chunks)):
+            host_recv = [None if t is None else torch.empty(t.shape, dtype=t.dtype) for t in recv_chunks]
+            self.exchange([None if t is None else t.cpu() for t in send_chunks], host_recv)
+            for q, (d, h) in enumerate(zip(recv_chunks, host_recv)):
+                if q != self.rank and d is not None and d.numel() > 0:
+                    d.copy_(h)
+            return
+        peer = (lambda q: q) if self.group is None else (lambda q: dist.get_global_rank(self.group, q))
+        ops = []
+        for q, t in enumerate(recv_chunks):
+            if q != self.rank and t is not None and t.numel() > 0:
+                ops.append(dist.P2POp(dist.irecv, t, peer(q), self.group))
+        for q, t in enumerate(send_chunks):
+            if q != self.rank and t is not None and t.numel() > 0:
+                ops.append(dist.P2POp(dist.isend, t, peer(q), self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
 
 
-def _all_reduce(t, group=None, op=dist.ReduceOp.SUM):
-    if _staged(t, group):
-        h = t.cpu()
-        dist.all_reduce(h, op=op, group=group)
-        t.copy_(h)
-    else:
-        dist.all_reduce(t, op=op, group=group)
-    return t
+def make_grid(world, rank, pv, pf):
+    """Process grid of pv vertex blocks x pf feature slices (pv * pf == world); rank = v * pf + f.
+    Returns (v, f, Comm of the pv ranks that share feature slice f).  Collective when pv > 1 and pf > 1
+    (every rank creates every sub-group, in the same order)."""
+    if pv * pf != world:
+        raise Exception("make_grid: pv * pf must equal the world size")
+    v, f = rank // pf, rank % pf
+    if pv == 1:
+        return v, f, Comm(solo=True)
+    if pf == 1:
+        return v, f, Comm(group=None)
+    mine = None
+    for ff in range(pf):
+        grp = dist.new_group([vv * pf + ff for vv in range(pv)])
+        if ff == f:
+            mine = grp
+    return v, f, Comm(group=mine)
 
 
-def _all_gather_vec(t, group=None):
-    world = dist.get_world_size(group)
-    src = t.cpu() if _staged(t, group) else t
-    table = [torch.zeros_like(src) for _ in range(world)]
-    dist.all_gather(table, src, group=group)
-    return [x.to(t.device) for x in table]
-
-
-def _exchange(send_chunks, recv_chunks, group=None):
-    """Pairwise exchange: send_chunks[q] goes to rank q, recv_chunks[q] is filled from rank q.
-    One batch of point-to-point operations (NCCL/RCCL: a single group call)."""
-    rank = dist.get_rank(group)
-    if any(_staged(t, group) for t in list(send_chunks) + list(recv_chunks)):
-        host_recv = [None if t is None else torch.empty(t.shape, dtype=t.dtype) for t in recv_chunks]
-        _exchange([None if t is None else t.cpu() for t in send_chunks], host_recv, group)
-        for q, (d, h) in enumerate(zip(recv_chunks, host_recv)):
-            if q != rank and d is not None and d.numel() > 0:
-                d.copy_(h)
-        return
-    ops = []
-    for q, t in enumerate(recv_chunks):
-        if q != rank and t is not None and t.numel() > 0:
-            ops.append(dist.P2POp(dist.irecv, t, q, group))
-    for q, t in enumerate(send_chunks):
-        if q != rank and t is not None and t.numel() > 0:
-            ops.append(dist.P2POp(dist.isend, t, q, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+def choose_grid(world, feats, min_slice=32):
+    """Feature columns propagate independently (filter.py:19-21 acts on every column of H alike), so
+    slicing them over ranks needs NO exchange; vertex blocks need a halo exchange per iteration.  Use as
+    many feature slices as keep >= min_slice columns per rank (128-byte gathers), vertex blocks for the rest."""
+    pf = 1
+    while pf * 2 <= world and world % (pf * 2) == 0 and feats % (pf * 2) == 0 and feats // (pf * 2) >= min_slice:
+        pf *= 2
+    return world // pf, pf
 
 
 def uniform_bounds(n_global, world):
@@ -132,13 +179,14 @@ class ShardState:
 class ShardedGraph:
     """This rank's shard of a symmetrically normalised, vertex-partitioned square graph."""
 
-    def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric"):
+    def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this
         rank owns (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.
-        Collective: every rank of ``group`` must call it."""
+        Collective: every rank of the vertex partition (``comm`` / ``group``) must call it."""
         self.backend = backend if backend is not None else NativeBackend()
-        self.group = group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.comm = comm if comm is not None else Comm(group=group)
+        self.group = self.comm.group
+        self.rank, self.world = self.comm.rank, self.comm.size
         be = self.backend
         dev = idx_global.device
         self.device = dev
@@ -156,7 +204,7 @@ class ShardedGraph:
         rowptr, colidx, raw = be.csr_arrays(g0)
         if normalized == "symmetric":
             deg = be.colsum(g0)
-            _all_reduce(deg, group)
+            self.comm.all_reduce(deg)
             D = be.degree_scale(deg, "symmetric")
             nvals = be.scale_values(g0, D[lo:hi], D)
         elif normalized == "none":
@@ -165,7 +213,7 @@ class ShardedGraph:
             raise Exception("Invalid matrix normalization")
         self.nnz_local = int(colidx.numel())
         t = torch.tensor([self.nnz_local], dtype=torch.int64, device=dev)
-        _all_reduce(t, group)
+        self.comm.all_reduce(t)
         self.nnz_global = int(t.item())
 
         # halo plan: distinct remote columns, sorted by global id (=> grouped by owner)
@@ -186,7 +234,7 @@ class ShardedGraph:
         bnd = torch.tensor(self.bounds[1:], dtype=torch.int64, device=dev)
         owner = torch.bucketize(halo, bnd, right=True)
         recv_counts = torch.bincount(owner, minlength=self.world).to(torch.int64)
-        table = _all_gather_vec(recv_counts, group)
+        table = self.comm.all_gather_vec(recv_counts)
         self.recv_counts = [int(c) for c in recv_counts.tolist()]
         self.send_counts = [int(table[q][self.rank]) for q in range(self.world)]
         roff = [0]
@@ -194,7 +242,7 @@ class ShardedGraph:
             roff.append(roff[-1] + c)
         want = [halo[roff[q]:roff[q + 1]].contiguous() for q in range(self.world)]      # ids I ask of q
         asked = [torch.empty(self.send_counts[q], dtype=torch.int64, device=dev) for q in range(self.world)]
-        _exchange(want, asked, group)
+        self.comm.exchange(want, asked)
         self.send_idx = (torch.cat(asked) - lo) if sum(self.send_counts) else torch.empty(0, dtype=torch.int64, device=dev)
         if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
             raise Exception("ShardedGraph: a peer asked for a row this rank does not own")
@@ -226,7 +274,7 @@ class ShardedGraph:
         packed = self.backend.gather_rows(local, self.send_idx) if self.send_idx.numel() else None
         sends = [packed[a:b] if packed is not None and b > a else None for a, b in self.send_slices]
         recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
-        _exchange(sends, recvs, self.group)
+        self.comm.exchange(sends, recvs)
 
     def step(self, state: ShardState, a: float):
         """One PPRIteration over the shard: halo exchange + fused SpMM/mix."""
@@ -245,7 +293,7 @@ class ShardedGraph:
 
     def halo_stats(self):
         t = torch.tensor([self.n_low + self.n_high, int(self.send_idx.numel()), self.n_local], dtype=torch.int64, device=self.device)
-        _all_reduce(t, self.group, dist.ReduceOp.MAX)
+        self.comm.all_reduce(t, dist.ReduceOp.MAX)
         return {"max_halo_rows": int(t[0]), "max_send_rows": int(t[1]), "max_local_rows": int(t[2])}
 
 
@@ -260,12 +308,17 @@ def _rmat_pairs(scale, m, gen, device, a=0.57, b=0.19, c=0.19):
     return src, dst
 
 
-def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=None, group=None):
+def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=None, group=None, grid=None):
     """Weak-scaling workload: a global R-MAT graph with nodes_per_rank * P vertices and about
-    entries_per_rank * P stored (symmetrised, de-duplicated) entries.  Every rank draws its share
-    of undirected edges, applies the same global vertex permutation, routes both directions of
-    every edge to the owner of its row, and builds its shard."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    entries_per_rank * P stored (symmetrised, de-duplicated) entries, on a pv x pf process grid
+    (default: pv = P vertex blocks, one feature slice).  Every rank draws its share of undirected edges;
+    the shares are all-gathered so that every rank sees the same global edge set, the same global vertex
+    permutation is applied, and each rank keeps the rows of its vertex block.
+    Returns (ShardedGraph, info, (v, f, pv, pf))."""
+    world_comm = Comm(group=group) if dist.is_initialized() else Comm(solo=True)
+    rank, world = world_comm.rank, world_comm.size
+    pv, pf = grid if grid is not None else (world, 1)
+    v, f, comm = make_grid(world, rank, pv, pf)
     N = nodes_per_rank * world
     t0 = time.time()
     gen = torch.Generator(device=device).manual_seed(seed * 1000003 + rank)
@@ -277,34 +330,32 @@ def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=Non
     s, d = s[keep], d[keep]
     keys = torch.unique(torch.minimum(s, d) * N + torch.maximum(s, d))
     del s, d, keep
+    # every rank receives every share (identical global edge set on all ranks)
+    counts = world_comm.all_gather_vec(torch.tensor([keys.numel()], dtype=torch.int64, device=device))
+    recvs = [keys if q == rank else torch.empty(int(counts[q]), dtype=torch.int64, device=device) for q in range(world)]
+    world_comm.exchange([keys] * world, recvs)
+    keys = torch.unique(torch.cat(recvs))                      # de-duplicate across shares
+    del recvs
     pgen = torch.Generator(device=device).manual_seed(3)
-    perm = torch.randperm(N, device=device, generator=pgen)          # identical on every rank
-    u, v = perm[keys // N], perm[keys % N]
+    perm = torch.randperm(N, device=device, generator=pgen)
+    if world > 1:                                              # the SAME permutation everywhere: rank 0's
+        if world_comm._staged(perm):
+            h = perm.cpu(); dist.broadcast(h, 0, group=group); perm.copy_(h)
+        else:
+            dist.broadcast(perm, 0, group=group)
+    bounds = uniform_bounds(N, pv)
+    lo, hi = bounds[v], bounds[v + 1]
+    u, w = perm[keys // N], perm[keys % N]
     del keys, perm
-    rows, cols = torch.cat([u, v]), torch.cat([v, u])
-    del u, v
-    owner = rows // nodes_per_rank
-    order = torch.argsort(owner)
-    packed = (rows * N + cols)[order]
-    counts = torch.bincount(owner, minlength=world).to(torch.int64)
-    del rows, cols, owner, order
-    table = _all_gather_vec(counts, group)
-    off = [0]
-    for c in counts.tolist():
-        off.append(off[-1] + int(c))
-    sends = [packed[off[q]:off[q + 1]] for q in range(world)]
-    recvs = [torch.empty(int(table[q][rank]), dtype=torch.int64, device=device) for q in range(world)]
-    recvs[rank] = sends[rank]
-    _exchange(sends, recvs, group)
-    mine = torch.unique(torch.cat(recvs))                             # de-duplicate across ranks
-    del packed, sends, recvs
-    idx = torch.stack([mine // N, mine % N], dim=1)
+    mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
+    idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
+    del u, w, mu, mw
     vals = torch.ones(idx.shape[0], dtype=torch.float32, device=device)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     t_gen = time.time() - t0
     t0 = time.time()
-    sg = ShardedGraph(idx, vals, uniform_bounds(N, world), backend=backend, group=group)
+    sg = ShardedGraph(idx, vals, bounds, backend=backend, comm=comm)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
-    return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2))
+    return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2)), (v, f, pv, pf)

@@ -65,6 +65,7 @@ def main():
     dev = torch.device("cuda:0" if on_gpu else "cpu")
     backend = None if on_gpu else OracleBackend()
     C, K, a = (64 if on_gpu else 12), 10, 0.1
+    pv, pf = world, 1
     if mode == "slices":
         n = 1003                                                   # not divisible by the world size
         coo, vals, shape = graphs.rmat_symmetric_coo(n, 9000, seed=5)
@@ -74,18 +75,23 @@ def main():
         lo, hi = bounds[rank], bounds[rank + 1]
         mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
         sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend)
-        H0_full = np.random.default_rng(1).uniform(-1, 1, size=(n, C)).astype(np.float32)
-        H0 = torch.from_numpy(H0_full[lo:hi].copy()).to(dev)
-    else:                                                          # the bench's distributed generator
-        sg, _ = sharded.build_rmat_shard(500, 6000, seed=1, device=dev, backend=backend)
+        v, f = rank, 0
+    else:                                                          # the bench's distributed generator on a pv x pf grid
+        if mode.startswith("grid"):
+            pv, pf = (int(x) for x in mode[4:].split("x"))
+        sg, _, (v, f, pv, pf) = sharded.build_rmat_shard(500, 6000, seed=1, device=dev, backend=backend, grid=(pv, pf))
         n, lo, hi = sg.n_global, sg.lo, sg.hi
-        H0 = torch.from_numpy(np.random.default_rng(10 + rank).uniform(-1, 1, size=(sg.n_local, C)).astype(np.float32)).to(dev)
+    cs = C // pf                                                   # this rank's feature slice
+    H0_full = np.random.default_rng(1).uniform(-1, 1, size=(n, C)).astype(np.float32)
+    H0 = torch.from_numpy(H0_full[lo:hi, f * cs:(f + 1) * cs].copy()).to(dev)
     state = sg.make_state(H0)
     out = sg.propagate(state, a, K).clone()
     again = sg.propagate(state, a, K).clone()
     assert torch.equal(out, again), "propagate is not repeatable"
     assert sg.n_buf == sg.n_low + sg.n_local + sg.n_high and sum(sg.recv_counts) == sg.n_low + sg.n_high
-    assert sg.recv_counts[rank] == 0 and sg.send_counts[rank] == 0
+    assert sg.recv_counts[sg.rank] == 0 and sg.send_counts[sg.rank] == 0 and sg.world == pv
+    if pv == 1:
+        assert sg.n_low + sg.n_high == 0                           # feature slices alone: no halo, no exchange
 
     # every rank's shard, mapped back to global ids (undoing the monotonic column remap)
     rowptr, colidx, nvals = (t.cpu().numpy() for t in sg.backend.csr_arrays(sg.graph))
@@ -96,11 +102,17 @@ def main():
                              halo[np.clip(pos - sg.n_local, 0, max(len(halo) - 1, 0))] if len(halo) else 0))
     grow = np.repeat(np.arange(sg.n_local), np.diff(rowptr)) + lo
     parts = [None] * world
-    dist.all_gather_object(parts, (grow, gcol, nvals, H0.cpu().numpy(), out.cpu().numpy()))
-    g_rows, g_cols = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
-    g_vals = np.concatenate([p[2] for p in parts])
-    H0_all, got_all = np.concatenate([p[3] for p in parts]), np.concatenate([p[4] for p in parts])
+    dist.all_gather_object(parts, (v, f, lo, hi, grow, gcol, nvals, out.cpu().numpy()))
+    first = sorted([p for p in parts if p[1] == 0], key=lambda p: p[0])     # one feature slice holds the whole graph once
+    g_rows, g_cols = np.concatenate([p[4] for p in first]), np.concatenate([p[5] for p in first])
+    g_vals = np.concatenate([p[6] for p in first])
+    got_all = np.zeros((n, C), dtype=np.float32)
+    for pv_, pf_, lo_, hi_, _, _, _, o in parts:
+        got_all[lo_:hi_, pf_ * cs:(pf_ + 1) * cs] = o
     assert len(g_rows) == sg.nnz_global
+    for p in parts:                                                # every feature slice of a vertex block holds the same shard
+        twin = [q for q in first if q[0] == p[0]][0]
+        assert np.array_equal(p[4], twin[4]) and np.array_equal(p[5], twin[5]) and np.array_equal(p[6], twin[6])
     if mode == "slices":
         raw_coo, raw_vals = coo, vals
     else:                                                          # generator: unit weights on the union of the shards' patterns
@@ -111,16 +123,16 @@ def main():
     ai, av = orc.get_adjacency(raw_coo, raw_vals, (n, n))
     _, _, want_vals = orc.coo_to_csr_coalesced(ai, av, (n, n))
     np.testing.assert_allclose(g_vals, want_vals, rtol=2e-6)       # normalised shard values == single-process normalisation
-    want = orc.appnp_propagate(raw_coo, raw_vals, (n, n), H0_all, a=a, iterations=K)
+    want = orc.appnp_propagate(raw_coo, raw_vals, (n, n), H0_full, a=a, iterations=K)
     np.testing.assert_allclose(got_all, want, rtol=1e-4, atol=1e-5)
     assert (got_all.argmax(1) == want.argmax(1)).all()
     if on_gpu:                                                     # against ONE GPU holding the whole graph: same summation order
         import gnntf
         whole = gnntf.normalize(gnntf.DeviceGraph(gnntf.SparseCOO(raw_coo, raw_vals, (n, n)), device=dev), "symmetric")
-        single = gnntf.appnp_propagate(whole, torch.from_numpy(H0_all).to(dev), a, K).cpu().numpy()
+        single = gnntf.appnp_propagate(whole, torch.from_numpy(H0_full).to(dev), a, K).cpu().numpy()
         np.testing.assert_allclose(got_all, single, rtol=1e-6, atol=1e-7)
     if rank == 0:
-        print("OK", mode, "world", world, "nnz", sg.nnz_global, "halo", sg.n_low + sg.n_high, "kernel", sg.graph.last_kernel())
+        print("OK", mode, "world", world, "grid", f"{pv}x{pf}", "nnz", sg.nnz_global, "halo", sg.n_low + sg.n_high, "kernel", sg.graph.last_kernel())
     dist.barrier()
     dist.destroy_process_group()
 

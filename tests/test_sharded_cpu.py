@@ -35,8 +35,21 @@ def test_distributed_generator_world2():
     launch(2, "rmat")
 
 
+@pytest.mark.parametrize("world,grid", [(2, "grid1x2"), (4, "grid2x2")])
+def test_feature_sliced_grid(world, grid):
+    """pv vertex blocks x pf feature slices: slices need no exchange (columns propagate independently)."""
+    launch(world, grid)
+
+
+def test_choose_grid():
+    from gnntf.sharded import choose_grid
+    assert choose_grid(8, 256) == (1, 8) and choose_grid(4, 256) == (1, 4) and choose_grid(2, 256) == (1, 2)
+    assert choose_grid(8, 128) == (2, 4) and choose_grid(8, 64) == (4, 2) and choose_grid(8, 7) == (8, 1)
+    assert choose_grid(1, 256) == (1, 1) and choose_grid(6, 96) == (3, 2)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["slices", "rmat"])
+@pytest.mark.parametrize("mode", ["slices", "rmat", "grid1x2"])
 def test_sharded_native_backend_two_ranks_one_gpu(mode):
     """The libgnx.so backend on real shards (rectangular local CSR, halo columns, output view inside
     the ping-pong buffer): two ranks share cuda:0 and exchange halos over gloo (staged through the host;
