@@ -143,6 +143,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the propagation path has no CPU fallback")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import gnntf
@@ -152,7 +153,11 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("GNX_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of several ranks on ONE card
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     K, C, a = args.iterations, args.feats, args.alpha
 
     if not sharded_path:

@@ -9,6 +9,8 @@ computed once per (normalized, add_eye) and cached, because it is constant.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 from . import sparse
@@ -103,3 +105,43 @@ class GCN(GNN):
         for latent_dim in latent_dims:
             self.add(layer_type(latent_dim, graph_dropout=0.5, dropout=0.5))
         self.add(layer_type(num_classes))
+
+
+class GCNIILayer(Layer):
+    """gcn.py:7-27: dropout(act(((1-a) A.H + a H0) . ((1-b) I + b W))), b = beta_transformer(l / (k+1)).
+    The propagation and the (1-a)/a mix are the same fused kernel as PPRIteration; the C x C
+    transform that follows is a dense library GEMM."""
+
+    def __build__(self, architecture, H0: Layer, a: float, l: float, k: int = 0, activation=linear,
+                  beta_transformer=math.log1p, dropout: float = 0.5, graph_dropout: float = 0.5, regularization=True):
+        width = architecture.top_shape()[1]
+        self.W = architecture.create_var((width, width), "zero", regularize=regularization)
+        self.a, self.l, self.k = a, l, k
+        self.activation = activation
+        self.dropout = dropout
+        self.graph_dropout = graph_dropout
+        self.H0 = H0
+        self.beta_transformer = beta_transformer
+        return architecture.top_shape()
+
+    def __forward__(self, gcn, features):
+        b = self.beta_transformer(self.l / (self.k + 1))
+        tradeoff = sparse.ppr_step(gcn.get_adjacency(self.graph_dropout), features, self.H0.value, self.a)
+        eye = torch.eye(self.W.shape[1], device=self.W.device, dtype=self.W.dtype)
+        return gcn.dropout(self.activation(torch.matmul(tradeoff, (1 - b) * eye + b * self.W)), self.dropout)
+
+
+class GCNII(GNN):
+    """gcn.py:54-74 -- http://proceedings.mlr.press/v119/chen20v/chen20v.pdf"""
+
+    def __init__(self, graph, features, num_classes, a: float = 0.1, l: float = 0.5, latent_dims=[64], iterations=64,
+                 dropout=0.6, convolution_regularization=True, layer_type=GCNIILayer, **kwargs):
+        super().__init__(graph, features, **kwargs)
+        self.add(Dropout(dropout))
+        for latent_dim in latent_dims:
+            self.add(Dense(latent_dim, dropout=0, activation=relu))
+        H0 = self.top_layer()
+        for iteration in range(iterations):
+            self.add(layer_type(H0, a, l, iteration, activation=relu, dropout=dropout, graph_dropout=0,
+                                regularization=convolution_regularization))
+        self.add(Dense(num_classes, dropout=0, regularize=False))

@@ -290,6 +290,21 @@ def gcn_forward_eval(indices, values, shape, X, weights, dtype=np.float32):
     return H
 
 
+def gcnii_forward_eval(indices, values, shape, X, dense_in, conv_W, dense_out, a=0.1, l=0.5, dtype=np.float32):
+    """GCNII in eval mode (gcn.py:54-74): Dropout [identity] -> Dense(relu) = H0 -> per layer k:
+    relu(((1-a) A_hat.H + a H0) . ((1-b) I + b W_k)), b = log1p(l/(k+1)) (gcn.py:22-27) -> Dense."""
+    ai, av = get_adjacency(indices, values, shape, training=False, dtype=dtype)
+    W, b = dense_in
+    H0 = dense_forward(np.asarray(X).astype(dtype), W.astype(dtype), b.astype(dtype), relu)
+    H = H0
+    for k, Wk in enumerate(conv_W):
+        beta = dtype(np.log1p(l / (k + 1)))
+        tradeoff = ppr_iteration(ai, av, shape, H, H0, a)
+        H = relu(tradeoff @ ((dtype(1) - beta) * np.eye(Wk.shape[1], dtype=dtype) + beta * Wk.astype(dtype)))
+    W, b = dense_out
+    return dense_forward(H, W.astype(dtype), b.astype(dtype))
+
+
 # --------------------------------------------------------------------------------------
 # A10  NodeClassification  (gnntf/core/gnn/graph_predictor.py:10-31)
 # --------------------------------------------------------------------------------------

@@ -260,6 +260,27 @@ def test_golden_arxiv_gcn_layer_api(gnntf, golden_dir):
     assert (out >= 0).all()
 
 
+def test_gcnii_layer_api(gnntf):
+    """GCNII reuses the fused SpMM+mix kernel (gcn.py:7-27,54-74)."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(1500, 12000, seed=4)
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((1500, 20)).astype(np.float32)
+    model = gnntf.GCNII(gnntf.SparseCOO(coo, vals, shape), X, num_classes=6, latent_dims=[32], iterations=8)
+    model.reset()
+    convs = [l for l in model.layers() if isinstance(l, gnntf.GCNIILayer)]
+    dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
+    for l in convs:      # the reference initialises W to zero (gcn.py:11); use non-trivial weights for the check
+        l.W.data.copy_(dev((rng.standard_normal((32, 32)) * 0.2).astype(np.float32)))
+    model.training_mode(False)
+    with torch.no_grad():
+        out = model(model.features).cpu().numpy()
+    want = orc.gcnii_forward_eval(coo, vals, shape, X, (dense[0].W.detach().cpu().numpy(), dense[0].b.detach().cpu().numpy()),
+                                  [l.W.detach().cpu().numpy() for l in convs],
+                                  (dense[1].W.detach().cpu().numpy(), dense[1].b.detach().cpu().numpy()), a=0.1, l=0.5)
+    np.testing.assert_allclose(out, want, rtol=RTOL, atol=ATOL)
+    assert len(convs) == 8 and [l.k for l in convs] == list(range(8))
+
+
 def test_train_and_predict_end_to_end(gnntf):
     """architecture.train()/predict() on the HIP path (README.md:26-68 usage), planted-partition graph."""
     gnntf.set_seed(0)

@@ -165,3 +165,16 @@ def test_flow_layers():
     assert c.value is a.value and t.output_shape == (5, 3)
     with pytest.raises(Exception, match="Mismatching trade-off dimentions"):
         gnntf.Layered((5, 3), [gnntf.Dense(2)]).add(gnntf.Tradeoff([a, gnntf.Layered((5, 3)).add(gnntf.Dense(2))]))
+
+
+def test_npz_dataset_roundtrip(tmp_path):
+    """Local-file replacement of the reference's dgl_setup tuple (experiment_setup.py:179)."""
+    G = nx.path_graph(5)
+    labels = np.array([0, 1, 0, 1, 0])
+    X = np.eye(5, dtype=np.float32)
+    path = str(tmp_path / "toy.npz")
+    gnntf.save_npz(path, G, labels, X, [0, 1], [2], [3, 4])
+    adj, l2, f2, train, valid, test = gnntf.load_npz(path)
+    want = gnntf.graph2adj(G)
+    assert adj.indices.tolist() == want.indices.tolist() and adj.dense_shape == (5, 5)
+    assert l2.tolist() == labels.tolist() and (f2 == X).all() and (train, valid, test) == ([0, 1], [2], [3, 4])
