@@ -278,6 +278,55 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial(const SpmmArgs p) {
     }
 }
 
+// Narrow features: a chunk's entries are dealt round-robin to the wave's 64/G sub-groups of G lanes
+// (each sub-group gathers whole C-wide rows), then the sub-group sums are added with a fixed xor tree.
+template <int VEC, int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_long_partial_group(const SpmmArgs p) {
+    constexpr int NS = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t chunk = (int64_t)blockIdx.x * 4 + wib;
+    if (chunk >= p.n_chunks) return;
+    const int32_t li = p.chunk_long[chunk];
+    const int64_t row = p.long_rows[li];
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t rend = p.rowptr[row + 1];
+    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    const int sub = lane / G;
+    const int c = (lane % G) * VEC;
+    const bool active = c < p.C;
+    const float *__restrict__ Xc = p.X + (active ? c : 0);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int64_t e = beg + sub; e < end; e += (int64_t)NS * U) {
+        float x[U][VEC];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t eu = e + (int64_t)u * NS;
+            if (eu < end) {
+                const int j = p.colidx[eu];
+                w[u] = p.vals[eu];
+                vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+            } else {
+                w[u] = 0.f;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
+    if (sub == 0 && active) vstore<VEC>(p.partial + chunk * (int64_t)p.C + c, acc);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
@@ -370,7 +419,12 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
 
 template <int VEC>
 void launch_long(const SpmmArgs &p, hipStream_t s) {
-    GNX_LAUNCH((k_spmm_long_partial<VEC, 8>), blocks_for(p.n_chunks, 4), p);
+    const int lanes = (p.C + VEC - 1) / VEC;
+    if (lanes > 32)      GNX_LAUNCH((k_spmm_long_partial<VEC, 8>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 16) GNX_LAUNCH((k_spmm_long_partial_group<VEC, 32, 4>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 8)  GNX_LAUNCH((k_spmm_long_partial_group<VEC, 16, 4>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 4)  GNX_LAUNCH((k_spmm_long_partial_group<VEC, 8, 4>), blocks_for(p.n_chunks, 4), p);
+    else                 GNX_LAUNCH((k_spmm_long_partial_group<VEC, 4, 4>), blocks_for(p.n_chunks, 4), p);
     GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
 }
 
