@@ -67,16 +67,49 @@ class PPRIteration(Layer):
         return self.activation(architecture.dropout(mixed, self.dropout))
 
 
+class PPRLoop(Layer):
+    """``iterations`` PPRIteration layers (filter.py:34-35) collapsed into one layer and one autograd node:
+    same arithmetic and the same sequence of edge-dropout masks as the layer-by-layer form, but no
+    per-iteration ``.value`` tensors and no stored activations for the backward (they are not needed: the
+    step is linear in H, and dropped adjacencies are regenerated from the counter RNG).  Opt-in through
+    ``APPNP(..., fused=True)``; only the default identity activation / zero feature dropout can be fused."""
+
+    def __build__(self, architecture: GNN, H0: Layer, restart_probability: float = 0.1, iterations: int = 10,
+                  graph_dropout: float = 0.5):
+        self.restart_probability = restart_probability
+        self.H0 = H0
+        self.iterations = iterations
+        self.graph_dropout = graph_dropout
+        return architecture.top_shape()
+
+    def __forward__(self, architecture: GNN, features):
+        if self.graph_dropout != 0 and architecture.is_training():
+            seed, first = architecture._next_mask_stream(self.iterations)
+            graph, p = architecture.graph, self.graph_dropout
+            make_adj = lambda k: sparse.normalize(graph, "symmetric", "none", p, seed, first + k)
+        else:
+            adj = architecture.get_adjacency(self.graph_dropout)
+            make_adj = lambda k: adj
+        if not torch.is_grad_enabled() and not (self.graph_dropout != 0 and architecture.is_training()):
+            return sparse.appnp_propagate(make_adj(0), self.H0.value, self.restart_probability, self.iterations)
+        return sparse.ppr_loop(make_adj, self.H0.value, self.restart_probability, self.iterations)
+
+
 class APPNP(GNN):
     """filter.py:25-35 -- https://arxiv.org/pdf/1810.05997.pdf"""
 
     def __init__(self, G, features, num_classes: int, a: float = 0.1, latent_dims=[64], iterations=10,
-                 dropout=0.6, graph_dropout=0.5, activation=linear, **kwargs):
+                 dropout=0.6, graph_dropout=0.5, activation=linear, fused=False, **kwargs):
         super().__init__(G, features, **kwargs)
         self.add(Dropout(0.5))
         for latent_dim in latent_dims:
             self.add(Dense(latent_dim, activation=relu, dropout=dropout))
         H0 = self.add(Dense(num_classes, regularize=False))
+        if fused:
+            if a is None or activation is not linear:
+                raise Exception("APPNP(fused=True) needs a float restart probability and the identity activation")
+            self.add(PPRLoop(H0, a, iterations, graph_dropout=graph_dropout))
+            return
         for _ in range(iterations):
             self.add(PPRIteration(H0, self.create_var() if a is None else a, graph_dropout=graph_dropout, activation=activation))
 

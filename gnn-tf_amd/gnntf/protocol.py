@@ -66,10 +66,10 @@ class Layered(VariableGenerator):
         return normalize(G.graph, "none", "none", dropout, seed, stream)
 
     # counter RNG bookkeeping for edge-dropout masks (one fresh stream id per call)
-    def _next_mask_stream(self):
+    def _next_mask_stream(self, n=1):
         from . import metrics
         count = getattr(self, "_mask_calls", 0)
-        self._mask_calls = count + 1
+        self._mask_calls = count + n
         return metrics.current_seed(), count
 
     def __call__(self, features):

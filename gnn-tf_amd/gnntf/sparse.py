@@ -206,6 +206,39 @@ class _PPRStep(torch.autograd.Function):
         return gH, gH0, None, None
 
 
+class _PPRLoop(torch.autograd.Function):
+    """K PPRIteration steps as ONE autograd node.  The step is linear in H, so the backward needs no
+    stored activations: g_k = (1-a) A_k^T g_{k+1}, dH0 = g_0 + a * sum_k g_{k+1}.  In training mode
+    every iteration has its own dropped + re-normalised adjacency A_k (filter.py:18 calls get_adjacency
+    each time); the counter RNG lets the backward REGENERATE A_k from (seed, stream id) instead of
+    keeping K value arrays alive."""
+
+    @staticmethod
+    def forward(ctx, H0, make_adj, a, K):
+        ctx.make_adj, ctx.a, ctx.K = make_adj, a, K
+        H0 = _as_f32_rows(H0).contiguous()
+        H = H0
+        for k in range(K):
+            H = _launch(make_adj(k), H, H0, 1.0 - a, a, nat.ACT_NONE)
+        return H
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gH0 = torch.zeros_like(g)
+        for k in range(ctx.K - 1, -1, -1):
+            gH0.add_(g, alpha=ctx.a)
+            g = _launch(ctx.make_adj(k), g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
+        gH0.add_(g)
+        return gH0, None, None, None
+
+
+def ppr_loop(make_adj, H0: torch.Tensor, a: float, iterations: int) -> torch.Tensor:
+    """``iterations`` fused PPR steps starting from H0; ``make_adj(k)`` returns the Adjacency of
+    iteration k (called again, with the same k, during the backward)."""
+    return _PPRLoop.apply(H0, make_adj, float(a), int(iterations))
+
+
 def spmm(adj: Adjacency, X: torch.Tensor) -> torch.Tensor:
     """Drop-in for tf.sparse.sparse_dense_matmul(adj, X); differentiable w.r.t. X."""
     return _SpMM.apply(X, adj)

@@ -281,6 +281,36 @@ def test_gcnii_layer_api(gnntf):
     assert len(convs) == 8 and [l.k for l in convs] == list(range(8))
 
 
+def test_fused_ppr_loop_equals_layers(gnntf):
+    """APPNP(fused=True): one autograd node for the K iterations, masks regenerated in the backward --
+    same outputs (bitwise) and gradients as the K separate PPRIteration layers, in training mode."""
+    coo, vals, shape = graphs.cora_shaped(seed=2)[:3]
+    X = np.random.default_rng(0).standard_normal((shape[0], 24)).astype(np.float32)
+    outs, grads = [], []
+    for fused in (False, True):
+        gnntf.set_seed(5)
+        model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, fused=fused)
+        torch.manual_seed(1)
+        model.reset()
+        dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
+        H0 = dev(np.random.default_rng(1).standard_normal((shape[0], 7)).astype(np.float32)).requires_grad_()
+        dense[-1].value = H0                                  # drive the propagation layers directly
+        feats = H0
+        with model:                                           # training mode: per-iteration edge dropout
+            for layer in model.layers()[len(model.layers()) - (1 if fused else 10):]:
+                feats = layer(model, feats)
+        (feats * dev(np.random.default_rng(2).standard_normal((shape[0], 7)).astype(np.float32))).sum().backward()
+        outs.append(feats.detach()); grads.append(H0.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(grads[0].cpu().numpy(), grads[1].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # eval mode goes through the single-call library loop
+    model.training_mode(False)
+    with torch.no_grad():
+        ev = model.layers()[-1](model, H0.detach())
+    adj = model.get_adjacency(0.5)
+    assert torch.equal(ev, gnntf.appnp_propagate(adj, H0.detach(), 0.1, 10))
+
+
 def test_train_and_predict_end_to_end(gnntf):
     """architecture.train()/predict() on the HIP path (README.md:26-68 usage), planted-partition graph."""
     gnntf.set_seed(0)
@@ -295,12 +325,13 @@ def test_train_and_predict_end_to_end(gnntf):
     G.add_edges_from((int(u), int(v)) for u, v in zip(src[keep], dst[keep]) if u != v)
     X = (np.eye(k)[labels] + rng.standard_normal((n, k)) * 1.5).astype(np.float32)
     train, valid, test = list(range(0, 200)), list(range(200, 500)), list(range(500, n))
-    model = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=k)
-    model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
-                patience=60, epochs=300)
-    accuracy = gnntf.acc(model.predict(gnntf.NodeClassification(test)), labels[test])
     mlp_like = (X[test].argmax(1) == labels[test]).mean()
-    assert accuracy > 0.7 and accuracy > mlp_like + 0.15       # propagation, not the features, does the work
+    for fused in (False, True):
+        model = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=k, fused=fused)
+        model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
+                    patience=60, epochs=300)
+        accuracy = gnntf.acc(model.predict(gnntf.NodeClassification(test)), labels[test])
+        assert accuracy > 0.7 and accuracy > mlp_like + 0.15       # propagation, not the features, does the work
 
 
 # ---- full-size properties (no oracle run at this size) ---------------------------------------------------------------
