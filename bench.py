@@ -229,7 +229,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"rmat_n{args.nodes}_nnz{args.entries}_C{C}_appnp_K{K}" + ("" if world == 1 else f"_per_gpu_x{world}"),
-                       "nodes_per_gpu": n_local, "stored_entries_per_gpu": nnz_local, "stored_entries_total": nnz_global,
+                       "rows_per_rank": n_local, "stored_entries_per_rank": nnz_local, "stored_entries_total": nnz_global,
                        "features": C, "iterations": K, "alpha": a, "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (sg.graph.last_kernel() if sharded_path else g.last_kernel())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -24,7 +24,7 @@ def one(pattern):
     files = glob.glob(pattern, recursive=True)
     if not files:
         raise SystemExit("no file matches " + pattern)
-    return files[0]
+    return max(files, key=os.path.getmtime)      # gpurun merges new runs beside old ones: take the newest
 
 
 def short(name):
