@@ -154,6 +154,12 @@ __global__ void k_make_tkeys(const int32_t *__restrict__ rowidx, const int32_t *
     payload[k] = (int32_t)k;
 }
 
+__global__ void k_permute_vals(const float *__restrict__ vals, const int32_t *__restrict__ perm, int64_t n,
+                               float *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = vals[perm[k]];
+}
+
 __global__ void k_split_tkeys(const uint64_t *__restrict__ keys, int64_t nnz, int64_t n_rows,
                               int32_t *__restrict__ t_row /* = column of A */, int32_t *__restrict__ t_col /* = row of A */) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,6 +252,7 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
     GNX_HIP(hipMalloc((void **)&t.colidx, (t.nnz ? t.nnz : 1) * sizeof(int32_t)));
     GNX_HIP(hipMalloc((void **)&g->t_perm, (t.nnz ? t.nnz : 1) * sizeof(int32_t)));
     GNX_HIP(hipMalloc((void **)&g->t_vals, (t.nnz ? t.nnz : 1) * sizeof(float)));
+    GNX_HIP(hipMalloc((void **)&g->t_raw, (t.nnz ? t.nnz : 1) * sizeof(float)));
     if (t.nnz == 0) {
         GNX_HIP(hipMemsetAsync(t.rowptr, 0, (t.n_rows + 1) * sizeof(int64_t), s));
         GNX_HIP(hipStreamSynchronize(s));
@@ -270,6 +277,7 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
                        trow.as<int32_t>(), t.colidx);
     hipLaunchKernelGGL(k_lower_bound_rows, dim3(blocks_for(t.n_rows + 1)), dim3(256), 0, s, trow.as<int32_t>(), t.nnz,
                        t.n_rows, t.rowptr);
+    hipLaunchKernelGGL(k_permute_vals, dim3(blocks_for(t.nnz)), dim3(256), 0, s, g->raw_vals, g->t_perm, t.nnz, g->t_raw);
     GNX_HIP(hipStreamSynchronize(s));
     int rc = build_long_plan(t, s);
     if (rc != GNX_OK) return rc;
@@ -303,6 +311,7 @@ int gnx_graph_destroy(gnx_graph_t g) {
     if (g->slot_ptr) (void)hipFree(g->slot_ptr);
     if (g->t_perm) (void)hipFree(g->t_perm);
     if (g->t_vals) (void)hipFree(g->t_vals);
+    if (g->t_raw) (void)hipFree(g->t_raw);
     if (g->partial) (void)hipFree(g->partial);
     if (g->deg) (void)hipFree(g->deg);
     delete g;

@@ -46,11 +46,22 @@ __device__ __forceinline__ float slot_value(const float *__restrict__ raw, const
     return acc;
 }
 
+// the same for position p of the transposed structure; without duplicates the raw value is read from
+// the transposed-order copy (a streaming read instead of a gather through t_perm)
+template <bool DROPOUT>
+__device__ __forceinline__ float t_value(const float *__restrict__ raw, const float *__restrict__ t_raw,
+                                         const int32_t *__restrict__ t_perm, const Drop &d, int64_t p, int32_t row, int32_t col) {
+    if (d.slot_ptr != nullptr) return slot_value<DROPOUT>(raw, d, t_perm[p], row, col);
+    const float v = t_raw[p];
+    if (!DROPOUT) return v;
+    return hash_u24(d.seed, d.stream, (uint64_t)row, (uint64_t)col, 0) >= d.thr ? v * d.scale : 0.f;
+}
+
 // column sums over the transposed structure: 8 lanes per column, fixed reduction tree.
 template <bool DROPOUT>
 __global__ void k_colsum_short(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
-                               const int32_t *__restrict__ t_perm, const float *__restrict__ raw, Drop d, int64_t n_cols,
-                               float *__restrict__ out) {
+                               const int32_t *__restrict__ t_perm, const float *__restrict__ raw,
+                               const float *__restrict__ t_raw, Drop d, int64_t n_cols, float *__restrict__ out) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t j = gid >> 3;
     const int sub = (int)(gid & 7);
@@ -60,7 +71,7 @@ __global__ void k_colsum_short(const int64_t *__restrict__ t_rowptr, const int32
         const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
         is_long = (e - b) > LONG_ROW;
         if (!is_long)
-            for (int64_t p = b + sub; p < e; p += 8) acc += slot_value<DROPOUT>(raw, d, t_perm[p], t_colidx[p], (int32_t)j);
+            for (int64_t p = b + sub; p < e; p += 8) acc += t_value<DROPOUT>(raw, t_raw, t_perm, d, p, t_colidx[p], (int32_t)j);
     }
     acc += __shfl_xor(acc, 4);
     acc += __shfl_xor(acc, 2);
@@ -71,13 +82,14 @@ __global__ void k_colsum_short(const int64_t *__restrict__ t_rowptr, const int32
 // one 256-thread block per long column; strided partial sums, then a fixed LDS tree.
 template <bool DROPOUT>
 __global__ __launch_bounds__(256) void k_colsum_long(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
-                                                     const int32_t *__restrict__ t_perm, const float *__restrict__ raw, Drop d,
+                                                     const int32_t *__restrict__ t_perm, const float *__restrict__ raw,
+                                                     const float *__restrict__ t_raw, Drop d,
                                                      const int32_t *__restrict__ long_rows, float *__restrict__ out) {
     __shared__ float red[256];
     const int32_t j = long_rows[blockIdx.x];
     const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
     float acc = 0.f;
-    for (int64_t p = b + threadIdx.x; p < e; p += 256) acc += slot_value<DROPOUT>(raw, d, t_perm[p], t_colidx[p], j);
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) acc += t_value<DROPOUT>(raw, t_raw, t_perm, d, p, t_colidx[p], j);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -149,11 +161,11 @@ int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t str
     if (t.n_rows == 0) return GNX_OK;
     const bool drop = dropout_p > 0.f;
     const unsigned nb = blocks_for(t.n_rows * 8);
-    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.n_rows, d_colsum_out);
-    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.n_rows, d_colsum_out);
+    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, d_colsum_out);
+    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, d_colsum_out);
     if (t.n_long > 0) {
-        if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.long_rows, d_colsum_out);
-        else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, d, t.long_rows, d_colsum_out);
+        if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
+        else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
     }
     GNX_HIP(hipGetLastError());
     return GNX_OK;
