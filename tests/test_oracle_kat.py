@@ -231,3 +231,21 @@ def test_golden_dropout_masks(golden_dir):
         np.testing.assert_array_equal(orc.keep_mask(coo, float(z["p"]), int(z["seed"]), stream), z[f"keep_{stream}"])
         _, av = orc.get_adjacency(coo, vals, (n, n), graph_dropout=float(z["p"]), training=True, seed=int(z["seed"]), stream=stream)
         np.testing.assert_array_equal(av, z[f"adj_vals_{stream}"])
+
+
+# ---- property test: random COO (duplicates, empty rows, rectangular) vs scipy in float64 --------------
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 40), st.integers(1, 40), st.integers(0, 300), st.integers(1, 9), st.integers(0, 2 ** 31 - 1))
+def test_property_spmm_matches_scipy(n_rows, n_cols, nnz, C, seed):
+    rng = np.random.default_rng(seed)
+    idx = np.stack([rng.integers(n_rows, size=nnz), rng.integers(n_cols, size=nnz)], axis=1).astype(np.int64)
+    vals = rng.standard_normal(nnz)
+    H = rng.standard_normal((n_cols, C))
+    want = sp.coo_matrix((vals, (idx[:, 0], idx[:, 1])), shape=(n_rows, n_cols)).tocsr() @ H
+    np.testing.assert_allclose(orc.sparse_dense_matmul(idx, vals, (n_rows, n_cols), H), want, rtol=1e-10, atol=1e-12)
+    rowptr, colidx, cvals = orc.coo_to_csr_coalesced(idx, vals, (n_rows, n_cols))
+    np.testing.assert_allclose(sp.csr_matrix((cvals, colidx, rowptr), shape=(n_rows, n_cols)) @ H, want, rtol=1e-10, atol=1e-12)
+    assert (np.diff(rowptr) >= 0).all() and all((np.diff(colidx[rowptr[i]:rowptr[i + 1]]) > 0).all() for i in range(n_rows))

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Config 2 timing (Cora-shaped APPNP, K=10, C=7): latency-bound regime.  ms per training epoch
+(layer-by-layer and fused) and eval forward latency on the HIP path, next to the numpy oracle's
+eval forward on the host."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd"), os.path.join(ROOT, "tests")]
+import numpy as np
+import torch
+import gnntf, graphs
+from oracle import gnntf_oracle as orc
+
+gnntf.set_default_device("cuda:0")
+coo, vals, shape, X = graphs.cora_shaped(seed=0)
+labels = np.random.default_rng(0).integers(0, 7, size=shape[0])
+train = list(range(140)); valid = list(range(140, 640))
+out = {}
+for fused in (False, True):
+    gnntf.set_seed(0)
+    model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, fused=fused)
+    model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]), epochs=5, patience=5)
+    torch.cuda.synchronize(); t0 = time.time()
+    model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]), epochs=100, patience=1000)
+    torch.cuda.synchronize()
+    out["train_ms_per_epoch_fused" if fused else "train_ms_per_epoch_layers"] = (time.time() - t0) * 10
+    with torch.no_grad():
+        for _ in range(5): model(model.features)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(100): model(model.features)
+        torch.cuda.synchronize()
+    out["eval_forward_ms_fused" if fused else "eval_forward_ms_layers"] = (time.time() - t0) * 10
+dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
+weights = [(l.W.detach().cpu().numpy(), l.b.detach().cpu().numpy()) for l in dense]
+t0 = time.time()
+for _ in range(3): orc.appnp_forward_eval(coo, vals, shape, X, weights)
+out["oracle_numpy_eval_forward_ms"] = (time.time() - t0) / 3 * 1e3
+print(json.dumps(out, indent=1))
