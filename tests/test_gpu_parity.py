@@ -61,6 +61,40 @@ def test_empty_and_invalid_graphs(gnntf):
         gnntf.spmm(adj, torch.ones(6, 3, device="cuda"))
 
 
+def test_c_abi_argument_errors_on_device(gnntf):
+    """Error convention of the boundary: int status + thread-local message, never a crash."""
+    from ctypes import byref, c_void_p
+    from gnntf import _native as nat
+    lib = nat.lib()
+    coo, vals, shape = graphs.random_coo(50, 50, 300, seed=2)
+    g = make_graph(gnntf, coo, vals, shape)
+    X = torch.rand(50, 16, device="cuda"); out = torch.empty_like(X)
+    s = nat.current_stream()
+    call = lambda *a: lib.gnx_spmm(g.handle, None, None, *a)
+    assert call(nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(X), 16, s) == -1 and b"alias" in lib.gnx_last_error()
+    assert call(nat.ptr(X), 8, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == -1 and b"leading dimension" in lib.gnx_last_error()
+    assert call(nat.ptr(X), 16, 0, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == -1 and b"feature width" in lib.gnx_last_error()
+    assert call(nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 7, nat.ptr(out), 16, s) == -1 and b"activation" in lib.gnx_last_error()
+    assert call(None, 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == -1 and b"NULL" in lib.gnx_last_error()
+    assert lib.gnx_appnp_propagate(g.handle, None, None, nat.ptr(X), 0.1, 3, 16, nat.ptr(X), nat.ptr(out), s) == -1
+    assert b"distinct" in lib.gnx_last_error()
+    assert lib.gnx_graph_normalize(g.handle, 1, 0, 1.5, 0, 0, nat.ptr(out), None, s) == -1 and b"dropout rate" in lib.gnx_last_error()
+    assert lib.gnx_graph_normalize(g.handle, 1, 2, 0.0, 0, 0, nat.ptr(out), None, s) == -1 and b"d_diag_out" in lib.gnx_last_error()
+    rect = make_graph(gnntf, *graphs.random_coo(20, 30, 100, seed=3))
+    assert lib.gnx_graph_normalize(rect.handle, 1, 0, 0.0, 0, 0, nat.ptr(out), None, s) == -1 and b"square" in lib.gnx_last_error()
+    bad = c_void_p()
+    rp = torch.tensor([0, 2, 1, 3], device="cuda"); ci = torch.tensor([0, 1, 2], dtype=torch.int32, device="cuda"); v = torch.ones(3, device="cuda")
+    assert lib.gnx_graph_create_csr(3, 3, 3, nat.ptr(rp), nat.ptr(ci), nat.ptr(v), s, byref(bad)) == -1 and b"valid sorted CSR" in lib.gnx_last_error()
+    # the library still works after the failed calls
+    assert call(nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == 0
+    want = orc.sparse_dense_matmul(coo, vals, shape, X.cpu().numpy())
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    # relu epilogue (GCN's default activation, gcn.py:78) and beta/alpha scaling
+    H0 = torch.rand(50, 16, device="cuda") - 0.5
+    assert call(nat.ptr(X), 16, 16, nat.ptr(H0), 16, -0.5, 2.0, 1, nat.ptr(out), 16, s) == 0
+    np.testing.assert_allclose(out.cpu().numpy(), np.maximum(-0.5 * want + 2.0 * H0.cpu().numpy(), 0), rtol=RTOL, atol=ATOL)
+
+
 # ---- A2: get_adjacency -------------------------------------------------------------------------------
 @pytest.mark.parametrize("norm", ["symmetric", "bipartite", "none"])
 @pytest.mark.parametrize("eye", ["none", "before", "after"])
