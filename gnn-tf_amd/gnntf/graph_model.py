@@ -178,3 +178,15 @@ class GCNII(GNN):
             self.add(layer_type(H0, a, l, iteration, activation=relu, dropout=dropout, graph_dropout=0,
                                 regularization=convolution_regularization))
         self.add(Dense(num_classes, dropout=0, regularize=False))
+
+
+class MLP(Trainable):
+    """The graph-free baseline (reference gnntf/core/nn/architectures/mlp.py:6-12): it falls out of the
+    generic layers; no propagation kernel is involved."""
+
+    def __init__(self, features, num_classes: int, latent_dims=[64], dropout: float = 0.5):
+        super().__init__(features)
+        self.add(Dropout(dropout))
+        for latent_dim in latent_dims:
+            self.add(Dense(latent_dim, dropout=dropout, activation=relu))
+        self.add(Dense(num_classes, regularize=False))

@@ -1,9 +1,16 @@
 """The Layer protocol and the Layered container -- the drop-in boundary of the hot path.
 
-Mirrors reference gnntf/core/nn/layered.py:5-86: deferred layer construction
-(__late_init__ -> __build__ returns the output shape), cached ``.value`` per layer, a
-training-mode flag that starts True and is cleared on leaving ``with architecture:``,
-feature dropout and edge ("sparse") dropout gated on that flag.
+API mirror of reference gnntf/core/nn/layered.py:5-86 (same public names, arguments, messages and
+quirks), written for torch tensors:
+
+  * a Layer is constructed with its arguments deferred; ``Layered.add`` binds it to the architecture
+    by calling ``__build__(architecture, *args, **kwargs)``, which must return the output shape
+    (layered.py:59-71); ``layer(architecture, x)`` runs ``__forward__`` and caches the result in
+    ``layer.value`` (layered.py:79-81), which other layers (PPRIteration's H0) read;
+  * the container keeps a training-mode flag that starts **True** and is only cleared when a
+    ``with architecture as variables:`` block exits (layered.py:9,37-42) -- so a forward before any
+    training runs with dropout on, exactly like the reference;
+  * feature dropout and edge ("sparse") dropout are gated on that flag (layered.py:44-50).
 """
 from __future__ import annotations
 
@@ -12,98 +19,110 @@ import torch
 from .params import VariableGenerator
 
 
-class Layered(VariableGenerator):
-    def __init__(self, input_shape, layers=list()):
-        super().__init__()
-        self.__layers = list()
-        self.__training_mode = True      # layered.py:9 -- True until the first `with` block exits
-        self.input_shape = tuple(input_shape)
-        for layer in layers:
-            self.add(layer)
-
-    def layers(self):
-        return self.__layers
-
-    def top_shape(self):
-        return self.__layers[-1].output_shape if self.__layers else self.input_shape
-
-    def top_layer(self):
-        return self.__layers[-1]
-
-    def add(self, layer):
-        if layer not in self.__layers:
-            layer.__late_init__(self)
-        self.__layers.append(layer)
-        return layer
-
-    def is_training(self):
-        return self.__training_mode
-
-    def training_mode(self, training_mode):
-        self.__training_mode = training_mode
-
-    def __enter__(self):
-        self.__training_mode = True
-        return [var.var for var in self.vars() if var.trainable]
-
-    def __exit__(self, type, value, tb):
-        self.__training_mode = False
-
-    def dropout(self, features, dropout=0.5):
-        """tf.nn.dropout(features, rate) in training mode, identity otherwise (layered.py:44-45)."""
-        if self.__training_mode and dropout != 0:
-            return torch.nn.functional.dropout(features, p=float(dropout), training=True)
-        return features
-
-    def sparse_dropout(self, G, dropout=0.5):
-        """Edge dropout (layered.py:47-50).  ``G`` is an Adjacency over raw values; in
-        training mode a new Adjacency is returned whose values were dropped per stored COO
-        entry on the device; otherwise G itself."""
-        if dropout == 0 or not self.__training_mode:
-            return G
-        from .sparse import normalize
-        seed, stream = self._next_mask_stream()
-        return normalize(G.graph, "none", "none", dropout, seed, stream)
-
-    # counter RNG bookkeeping for edge-dropout masks (one fresh stream id per call)
-    def _next_mask_stream(self, n=1):
-        from . import metrics
-        count = getattr(self, "_mask_calls", 0)
-        self._mask_calls = count + n
-        return metrics.current_seed(), count
-
-    def __call__(self, features):
-        for layer in self.__layers:
-            features = layer(self, features)
-        return features
-
-
 class Layer(object):
+    """Base class of every layer.  Subclasses implement ``__build__`` and ``__forward__``."""
+
     def __init__(self, *args, output_regularize: float = 0, **kwargs):
-        self.__args = args
-        self.__kwargs = kwargs
+        self._pending = (args, kwargs)          # consumed by __late_init__
         self.output_regularize = output_regularize
 
-    def __late_init__(self, architecture: VariableGenerator):
-        before = set(architecture.vars())
-        self.output_shape = self.__build__(architecture, *self.__args, **self.__kwargs)
-        if self.output_shape is None:
-            raise Exception("Layer __build__ should return an output shape")
-        self.vars = set(architecture.vars()) - before
-        self.__args = None
-        self.__kwargs = None
-
+    # -- to be provided by subclasses ------------------------------------------------------------
     def __build__(self, architecture: VariableGenerator, *args, **kwargs):
         raise Exception("Layer should implment a __build__ method")
 
     def __forward__(self, architecture: VariableGenerator, features):
         raise Exception("Layer should implement a __forward__ method")
 
+    # -- protocol ------------------------------------------------------------------------------------
+    def __late_init__(self, architecture: VariableGenerator):
+        """Binds the layer: runs __build__ with the deferred arguments, records the output shape and
+        which variables the layer created (layered.py:64-71)."""
+        args, kwargs = self._pending
+        known = set(architecture.vars())
+        shape = self.__build__(architecture, *args, **kwargs)
+        if shape is None:
+            raise Exception("Layer __build__ should return an output shape")
+        self.output_shape = shape
+        self.vars = set(architecture.vars()) - known
+        self._pending = None
+
     def __call__(self, architecture: VariableGenerator, features):
         self.value = self.__forward__(architecture, features)
         return self.value
 
     def loss(self):
+        """output_regularize * tf.nn.l2_loss(value) = output_regularize * sum(value^2)/2 (layered.py:83-86)."""
         if self.output_regularize == 0:
             return 0
-        return self.output_regularize * (self.value ** 2).sum() / 2   # tf.nn.l2_loss
+        return self.output_regularize * (self.value ** 2).sum() / 2
+
+
+class Layered(VariableGenerator):
+    """Sequential container of layers + variable registry + training-mode switch."""
+
+    def __init__(self, input_shape, layers=list()):
+        super().__init__()
+        self.input_shape = tuple(input_shape)
+        self._stack = []
+        self._training = True                    # layered.py:9
+        self._mask_calls = 0                     # edge-dropout mask streams handed out so far
+        for layer in layers:
+            self.add(layer)
+
+    # -- structure -------------------------------------------------------------------------------------
+    def add(self, layer):
+        if not any(layer is known for known in self._stack):
+            layer.__late_init__(self)
+        self._stack.append(layer)
+        return layer
+
+    def layers(self):
+        return self._stack
+
+    def top_layer(self):
+        return self._stack[-1]
+
+    def top_shape(self):
+        return self._stack[-1].output_shape if self._stack else self.input_shape
+
+    def __call__(self, features):
+        for layer in self._stack:
+            features = layer(self, features)
+        return features
+
+    # -- training mode -----------------------------------------------------------------------------------
+    def is_training(self):
+        return self._training
+
+    def training_mode(self, training_mode):
+        self._training = training_mode
+
+    def __enter__(self):
+        self._training = True
+        return [v.var for v in self.vars() if v.trainable]
+
+    def __exit__(self, type, value, tb):
+        self._training = False
+
+    # -- dropout -------------------------------------------------------------------------------------------
+    def dropout(self, features, dropout=0.5):
+        """tf.nn.dropout(features, rate) while training, identity otherwise (layered.py:44-45)."""
+        if not self._training or dropout == 0:
+            return features
+        return torch.nn.functional.dropout(features, p=float(dropout), training=True)
+
+    def sparse_dropout(self, G, dropout=0.5):
+        """Edge dropout (layered.py:47-50).  ``G`` is an Adjacency; while training a NEW Adjacency is
+        returned whose raw values were dropped per stored COO entry on the device, otherwise G itself."""
+        if dropout == 0 or not self._training:
+            return G
+        from .sparse import normalize
+        seed, stream = self._next_mask_stream()
+        return normalize(G.graph, "none", "none", dropout, seed, stream)
+
+    def _next_mask_stream(self, n=1):
+        """(seed, first stream id) of the next ``n`` edge-dropout masks of the counter RNG."""
+        from . import metrics
+        first = self._mask_calls
+        self._mask_calls = first + n
+        return metrics.current_seed(), first

@@ -17,13 +17,7 @@ def cpu_default():
     gnntf.set_default_device(None)
 
 
-class MLP(gnntf.Trainable):  # reference gnntf/core/nn/architectures/mlp.py:6-12
-    def __init__(self, features, num_classes, latent_dims=[16], dropout=0.5):
-        super().__init__(features)
-        self.add(gnntf.Dropout(dropout))
-        for d in latent_dims:
-            self.add(gnntf.Dense(d, activation=gnntf.relu, dropout=dropout))
-        self.add(gnntf.Dense(num_classes, regularize=False))
+MLP = gnntf.MLP   # reference gnntf/core/nn/architectures/mlp.py:6-12
 
 
 def test_layer_protocol_and_shapes():
