@@ -179,7 +179,7 @@ def main():
         if args.grid:
             grid = tuple(int(x) for x in args.grid.split("x"))
         else:
-            grid = sharded.choose_grid(world, C)
+            grid = sharded.choose_grid(world, C, args.nodes * world, args.entries * world)
         sg, prep, (gv, gf, pv, pf) = sharded.build_rmat_shard(args.nodes, args.entries, seed=1, device=device, grid=grid)
         n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
         C_local = C // pf                                                       # this rank's feature slice

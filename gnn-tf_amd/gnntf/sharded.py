@@ -2,7 +2,7 @@
 
 Feature columns propagate independently (the step acts on every column of H alike), so slicing the
 columns over ranks needs no exchange at all; vertex blocks need the halo exchange described below.
-choose_grid() takes feature slices while they stay >= 32 columns wide and vertex blocks for the rest.
+choose_grid() picks the grid with a small measured cost model (grid_cost_ms).
 
 The reference has no distributed code at all; this module is the
 multi-GPU form of the same hot path -- PPRIteration.__forward__ (reference
@@ -155,14 +155,33 @@ def make_grid(world, rank, pv, pf):
     return v, f, Comm(group=mine)
 
 
-def choose_grid(world, feats, min_slice=32):
-    """Feature columns propagate independently (filter.py:19-21 acts on every column of H alike), so
-    slicing them over ranks needs NO exchange; vertex blocks need a halo exchange per iteration.  Use as
-    many feature slices as keep >= min_slice columns per rank (128-byte gathers), vertex blocks for the rest."""
-    pf = 1
-    while pf * 2 <= world and world % (pf * 2) == 0 and feats % (pf * 2) == 0 and feats // (pf * 2) >= min_slice:
-        pf *= 2
-    return world // pf, pf
+def grid_cost_ms(pv, pf, feats, nodes_total, entries_total, link_GBs=60.0, halo_frac=0.16):
+    """Estimated time of ONE propagation iteration on a pv x pf grid, from round-1 measurements on MI355X:
+      * compute: entries per rank x (5.5 + 0.61 * max(w, 32)) ps, w = columns per rank -- the fused kernel's
+        measured cost (RMAT 10M/100M: 2.5 / 4.5 / 8.6 / 16.3 ms at w = 32 / 64 / 128 / 256; below 32 columns a
+        gather still moves one 128-byte line, so narrower slices are not cheaper);
+      * exchange (pv > 1 only): halo_frac * nodes_total rows of 4w bytes arrive per rank over its pv - 1 links
+        (one xGMI link per peer, link_GBs per direction).  halo_frac = 0.16 is what a random 1-D partition of
+        the RMAT workload needs (tools/sim_grid.py: 12.4-14.5M rows of 80M); it is graph dependent."""
+    w = max(feats // pf, 1)
+    compute = entries_total / pv * (5.5 + 0.61 * max(w, 32)) * 1e-9
+    comm = 0.0 if pv == 1 else halo_frac * nodes_total * 4.0 * w / ((pv - 1) * link_GBs * 1e9) * 1e3
+    return compute + comm
+
+
+def choose_grid(world, feats, nodes_total=80_000_000, entries_total=800_000_000, **model):
+    """Feature columns propagate independently (filter.py:19-21 acts on every column of H alike), so slicing
+    them over ranks needs NO exchange, while vertex blocks pay a halo exchange per iteration but keep rows
+    wide.  Picks the pv x pf factorisation of ``world`` (pf dividing ``feats``) with the lowest grid_cost_ms."""
+    best = None
+    for pf in range(1, world + 1):
+        if world % pf or feats % pf:
+            continue
+        pv = world // pf
+        cost = grid_cost_ms(pv, pf, feats, nodes_total, entries_total, **model)
+        if best is None or cost < best[0] - 1e-12:
+            best = (cost, pv, pf)
+    return best[1], best[2]
 
 
 def uniform_bounds(n_global, world):

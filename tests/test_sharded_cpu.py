@@ -42,10 +42,17 @@ def test_feature_sliced_grid(world, grid):
 
 
 def test_choose_grid():
-    from gnntf.sharded import choose_grid
-    assert choose_grid(8, 256) == (1, 8) and choose_grid(4, 256) == (1, 4) and choose_grid(2, 256) == (1, 2)
-    assert choose_grid(8, 128) == (2, 4) and choose_grid(8, 64) == (4, 2) and choose_grid(8, 7) == (8, 1)
-    assert choose_grid(1, 256) == (1, 1) and choose_grid(6, 96) == (3, 2)
+    """Cost model of DESIGN.md section 5: wide features -> slices (no exchange); medium -> vertex blocks."""
+    from gnntf.sharded import choose_grid, grid_cost_ms
+    for world in (2, 4, 8):
+        assert choose_grid(world, 256, 10_000_000 * world, 100_000_000 * world) == (1, world)
+    assert choose_grid(8, 128, 80_000_000, 800_000_000) == (1, 8)
+    assert choose_grid(8, 64, 80_000_000, 800_000_000) == (8, 1)
+    assert choose_grid(8, 7, 80_000_000, 800_000_000) == (8, 1)          # 7 columns cannot be sliced
+    assert choose_grid(1, 256) == (1, 1)
+    assert choose_grid(8, 256, 80_000_000, 800_000_000, link_GBs=1e6) == (8, 1)   # free links -> keep rows wide
+    assert abs(grid_cost_ms(1, 8, 256, 80_000_000, 800_000_000) - 20.0) < 1.0      # measured: 22.3 ms
+    assert abs(grid_cost_ms(1, 1, 256, 10_000_000, 100_000_000) - 16.2) < 0.5      # measured: 16.2 ms
 
 
 @pytest.mark.gpu
