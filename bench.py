@@ -138,6 +138,11 @@ def cpu_baseline(g, H0, args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: anything native libraries print there (RCCL's version banner)
+    # is sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,7 +245,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(g, H0, args)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     if sharded_path:
         dist.barrier()
         dist.destroy_process_group()
