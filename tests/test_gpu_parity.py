@@ -108,6 +108,33 @@ def test_normalize_options(gnntf, norm, eye):
     np.testing.assert_allclose(gnntf.spmm(adj, dev(H)).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("norm", ["symmetric", "bipartite", "none"])
+@pytest.mark.parametrize("eye", ["none", "before", "after"])
+def test_normalize_options_with_edge_dropout(gnntf, norm, eye):
+    """Training mode: dropout first, then +I / scaling on the DROPPED values (gnn.py:37-49), duplicates included."""
+    coo, vals, shape = graphs.random_coo(200, 200, 2500, seed=33, weighted=True, dup_frac=0.3)
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, norm, eye, dropout=0.3, seed=11, stream_id=5)
+    ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=0.3, normalized=norm, add_eye=eye, training=True, seed=11, stream=5,
+                               dtype=np.float64)
+    H = np.random.default_rng(2).standard_normal((200, 9)).astype(np.float32)
+    want = orc.sparse_dense_matmul(ai, av, shape, H.astype(np.float64))
+    np.testing.assert_allclose(gnntf.spmm(adj, dev(H)).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+def test_nan_semantics_match(gnntf):
+    """Negative column sums: sqrt gives NaN in TensorFlow and here alike (no silent clamping); zero sums give 0."""
+    idx = np.array([[0, 1], [1, 0], [1, 2], [2, 1], [3, 3]])
+    vals = np.array([1.0, 1.0, -3.0, -3.0, 0.0], dtype=np.float32)       # column sums: 1, -2, -3, 0
+    g = make_graph(gnntf, idx, vals, (4, 4))
+    got = gnntf.normalize(g, "symmetric").vals.cpu().numpy()
+    with np.errstate(invalid="ignore"):
+        _, want = orc.get_adjacency(idx, vals, (4, 4))
+    _, _, want = orc.coo_to_csr_coalesced(idx, want, (4, 4))
+    assert np.isnan(got).tolist() == np.isnan(want).tolist() and np.isnan(got).any()
+    assert got[-1] == 0 and want[-1] == 0                                 # divide_no_nan(1, 0) = 0 on the zero column
+
+
 def test_hand_graphs(gnntf):
     """KAT-2 on the device: isolated nodes -> a*H0; doubled COO == single COO; directed column-sum rule."""
     idx, vals, shape = orc.graph2adj(range(8), [(0, i) for i in range(1, 6)])
