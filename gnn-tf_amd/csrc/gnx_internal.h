@@ -34,8 +34,11 @@ void set_error(const char *fmt, ...);
 // Rows whose entry count exceeds LONG_ROW are cut into chunks of LONG_CHUNK entries that
 // separate waves sum into a partial slab; a second kernel adds a row's partials in chunk
 // order (fixed order => bitwise reproducible) and applies the epilogue.
-constexpr int LONG_ROW = 512;
-constexpr int LONG_CHUNK = 512;
+#ifndef GNX_LONG_ROW
+#define GNX_LONG_ROW 512
+#endif
+constexpr int LONG_ROW = GNX_LONG_ROW;
+constexpr int LONG_CHUNK = GNX_LONG_ROW;
 
 // One CSR-like structure (the matrix itself, or its transpose).
 struct Csr {
