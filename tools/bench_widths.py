@@ -7,7 +7,7 @@ import argparse
 import json
 import os
 import sys
-import time
+
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd")]
