@@ -95,6 +95,46 @@ def test_c_abi_argument_errors_on_device(gnntf):
     np.testing.assert_allclose(out.cpu().numpy(), np.maximum(-0.5 * want + 2.0 * H0.cpu().numpy(), 0), rtol=RTOL, atol=ATOL)
 
 
+def test_c_client_of_the_abi(tmp_path):
+    """include/gnx.h + libgnx.so from a plain C program (no Python, no torch in the process)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_smoke")
+    lib = os.path.join(root, "gnn-tf_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi_smoke.c"), "-L", lib, "-lgnx", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "C ABI OK" in res.stdout, res.stdout + res.stderr
+
+
+def test_random_shapes_against_oracle(gnntf):
+    """Seeded fuzz over shapes, widths, leading dimensions, duplicates and empty rows (all dispatch classes)."""
+    rng = np.random.default_rng(2024)
+    kernels = set()
+    for case in range(60):
+        n_rows, n_cols = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        nnz = int(rng.integers(0, 4000))
+        C = int(rng.choice([1, 2, 3, 4, 5, 8, 12, 17, 31, 32, 33, 48, 64, 65, 96, 128, 129, 160, 256, 300]))
+        pad = int(rng.choice([0, 0, 1, 4, 7]))
+        idx = np.stack([rng.integers(n_rows, size=nnz), rng.integers(n_cols, size=nnz)], axis=1).astype(np.int64)
+        if nnz and rng.random() < 0.5:                                   # a heavy row now and then
+            idx[: nnz // 2, 0] = int(rng.integers(n_rows))
+        vals = rng.standard_normal(nnz).astype(np.float32)
+        g = make_graph(gnntf, idx, vals, (n_rows, n_cols))
+        X = rng.standard_normal((n_cols, C + pad)).astype(np.float32)
+        H0 = rng.standard_normal((n_rows, C + pad)).astype(np.float32)
+        Xd, H0d = dev(X)[:, :C], dev(H0)[:, :C]
+        from gnntf.sparse import _launch
+        got = _launch(gnntf.Adjacency(g), Xd, H0d, 0.75, 0.25, 1 if case % 3 == 0 else 0).cpu().numpy()
+        want = orc.sparse_dense_matmul(idx, vals.astype(np.float64), (n_rows, n_cols), X[:, :C].astype(np.float64)) * 0.75 + 0.25 * H0[:, :C]
+        if case % 3 == 0:
+            want = np.maximum(want, 0)
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4, err_msg=f"case {case}: {n_rows}x{n_cols} nnz={nnz} C={C} pad={pad}")
+        kernels.add(g.last_kernel())
+    assert kernels >= {"spmm_wave", "spmm_group32", "spmm_group16", "spmm_group8", "spmm_group4"}
+
+
 # ---- A2: get_adjacency -------------------------------------------------------------------------------
 @pytest.mark.parametrize("norm", ["symmetric", "bipartite", "none"])
 @pytest.mark.parametrize("eye", ["none", "before", "after"])
