@@ -261,9 +261,10 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
         g->has_t = true;
         return GNX_OK;
     }
-    DevBuf k0, k1, p0, trow, tmp;
+    DevBuf k0, k1, p0, tmp;
     GNX_HIP(k0.alloc(t.nnz * 8)); GNX_HIP(k1.alloc(t.nnz * 8));
-    GNX_HIP(p0.alloc(t.nnz * 4)); GNX_HIP(trow.alloc(t.nnz * 4));
+    GNX_HIP(p0.alloc(t.nnz * 4));
+    GNX_HIP(hipMalloc((void **)&g->t_rowidx, t.nnz * sizeof(int32_t)));
     hipLaunchKernelGGL(k_make_tkeys, dim3(blocks_for(t.nnz)), dim3(256), 0, s, g->rowidx, a.colidx, a.nnz, a.n_rows,
                        k0.as<uint64_t>(), p0.as<int32_t>());
     const unsigned end_bit = bits_for((uint64_t)a.n_rows * (uint64_t)a.n_cols);
@@ -274,8 +275,8 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
     GNX_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<int32_t>(), g->t_perm,
                                       (size_t)t.nnz, 0u, end_bit, s));
     hipLaunchKernelGGL(k_split_tkeys, dim3(blocks_for(t.nnz)), dim3(256), 0, s, k1.as<uint64_t>(), t.nnz, a.n_rows,
-                       trow.as<int32_t>(), t.colidx);
-    hipLaunchKernelGGL(k_lower_bound_rows, dim3(blocks_for(t.n_rows + 1)), dim3(256), 0, s, trow.as<int32_t>(), t.nnz,
+                       g->t_rowidx, t.colidx);
+    hipLaunchKernelGGL(k_lower_bound_rows, dim3(blocks_for(t.n_rows + 1)), dim3(256), 0, s, g->t_rowidx, t.nnz,
                        t.n_rows, t.rowptr);
     hipLaunchKernelGGL(k_permute_vals, dim3(blocks_for(t.nnz)), dim3(256), 0, s, g->raw_vals, g->t_perm, t.nnz, g->t_raw);
     GNX_HIP(hipStreamSynchronize(s));
@@ -312,6 +313,7 @@ int gnx_graph_destroy(gnx_graph_t g) {
     if (g->t_perm) (void)hipFree(g->t_perm);
     if (g->t_vals) (void)hipFree(g->t_vals);
     if (g->t_raw) (void)hipFree(g->t_raw);
+    if (g->t_rowidx) (void)hipFree(g->t_rowidx);
     if (g->partial) (void)hipFree(g->partial);
     if (g->deg) (void)hipFree(g->deg);
     delete g;

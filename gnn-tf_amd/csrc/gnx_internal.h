@@ -72,6 +72,7 @@ struct gnx_graph {
     int32_t *t_perm = nullptr;   // [a.nnz] coalesced slot of every transposed entry
     float *t_vals = nullptr;     // [a.nnz] scratch: values gathered into transposed order
     float *t_raw = nullptr;      // [a.nnz] raw values in transposed order (streaming column sums)
+    int32_t *t_rowidx = nullptr; // [a.nnz] row of the transposed structure (= column of A) per transposed position
     // partial slab for long rows (grown on demand)
     float *partial = nullptr;
     size_t partial_bytes = 0;

@@ -122,6 +122,22 @@ __global__ void k_scale_values(const int32_t *__restrict__ rowidx, const int32_t
     out[k] = v;
 }
 
+// the same values written in the order of the transposed structure: position p holds entry
+// (row = t_colidx[p], col = t_rowidx[p]) of A
+template <bool DROPOUT>
+__global__ void k_scale_values_t(const int32_t *__restrict__ t_rowidx, const int32_t *__restrict__ t_colidx,
+                                 const int32_t *__restrict__ t_perm, const float *__restrict__ raw,
+                                 const float *__restrict__ t_raw, Drop d, const float *__restrict__ rs,
+                                 const float *__restrict__ cs, int64_t nnz, float *__restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const int32_t r = t_colidx[p], c = t_rowidx[p];
+    float v = t_value<DROPOUT>(raw, t_raw, t_perm, d, p, r, c);
+    if (rs) v = rs[r] * v;
+    if (cs) v = v * cs[c];
+    out[p] = v;
+}
+
 // diagonal weight of the identity added by add_eye (gnn.py:39,49)
 __global__ void k_diag(const float *__restrict__ deg, int64_t n, int mode /*0: ones, 1: deg^2, 2: deg*/, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,22 +214,40 @@ int gnx_graph_scale_values(gnx_graph_t g, float dropout_p, uint64_t seed, uint64
     return GNX_OK;
 }
 
-int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed, uint64_t stream_id,
-                        float *d_vals_out, float *d_diag_out, void *stream) {
-    GNX_CHECK_ARG(g != nullptr, "gnx_graph_normalize: NULL handle");
+static int scale_values_any(gnx_graph_t g, bool transposed, float dropout_p, uint64_t seed, uint64_t stream_id,
+                            const float *rs, const float *cs, float *out, void *stream) {
+    if (!transposed) return gnx_graph_scale_values(g, dropout_p, seed, stream_id, rs, cs, out, stream);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    Drop d;
+    rc = make_drop(g, dropout_p, seed, stream_id, d);
+    if (rc != GNX_OK) return rc;
+    if (g->a.nnz == 0) return GNX_OK;
+    const unsigned nb = blocks_for(g->a.nnz);
+    if (dropout_p > 0.f) hipLaunchKernelGGL(k_scale_values_t<true>, dim3(nb), dim3(256), 0, s, g->t_rowidx, g->t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, rs, cs, g->a.nnz, out);
+    else                 hipLaunchKernelGGL(k_scale_values_t<false>, dim3(nb), dim3(256), 0, s, g->t_rowidx, g->t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, rs, cs, g->a.nnz, out);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+static int normalize_impl(const char *fn, gnx_graph_t g, bool transposed, int normalized, int add_eye, float dropout_p,
+                          uint64_t seed, uint64_t stream_id, float *d_vals_out, float *d_diag_out, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "%s: NULL handle", fn);
     GNX_CHECK_ARG(normalized == GNX_NORM_NONE || normalized == GNX_NORM_SYMMETRIC || normalized == GNX_NORM_BIPARTITE,
                   "Invalid matrix normalization");
     GNX_CHECK_ARG(add_eye == GNX_EYE_NONE || add_eye == GNX_EYE_BEFORE || add_eye == GNX_EYE_AFTER,
-                  "gnx_graph_normalize: invalid add_eye %d", add_eye);
-    GNX_CHECK_ARG(add_eye == GNX_EYE_NONE || d_diag_out != nullptr, "gnx_graph_normalize: add_eye needs d_diag_out");
+                  "%s: invalid add_eye %d", fn, add_eye);
+    GNX_CHECK_ARG(g->a.nnz == 0 || d_vals_out != nullptr, "%s: NULL output", fn);
+    GNX_CHECK_ARG(add_eye == GNX_EYE_NONE || d_diag_out != nullptr, "%s: add_eye needs d_diag_out", fn);
     GNX_CHECK_ARG((normalized == GNX_NORM_NONE && add_eye == GNX_EYE_NONE) || g->a.n_rows == g->a.n_cols,
-                  "gnx_graph_normalize: normalisation / add_eye need a square graph (%lld x %lld)",
+                  "%s: normalisation / add_eye need a square graph (%lld x %lld)", fn,
                   (long long)g->a.n_rows, (long long)g->a.n_cols);
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = g->a.n_rows;
     int rc;
     if (normalized == GNX_NORM_NONE) {
-        rc = gnx_graph_scale_values(g, dropout_p, seed, stream_id, nullptr, nullptr, d_vals_out, stream);
+        rc = scale_values_any(g, transposed, dropout_p, seed, stream_id, nullptr, nullptr, d_vals_out, stream);
         if (rc != GNX_OK) return rc;
         if (add_eye != GNX_EYE_NONE && n > 0)
             hipLaunchKernelGGL(k_diag, dim3(blocks_for(n)), dim3(256), 0, s, (const float *)nullptr, n, 0, d_diag_out);
@@ -226,8 +260,8 @@ int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropou
     if (rc != GNX_OK) return rc;
     rc = gnx_degree_scale(g->deg, g->a.n_cols, normalized, add_eye == GNX_EYE_BEFORE, stream);
     if (rc != GNX_OK) return rc;
-    rc = gnx_graph_scale_values(g, dropout_p, seed, stream_id, g->deg, normalized == GNX_NORM_SYMMETRIC ? g->deg : nullptr,
-                                d_vals_out, stream);
+    rc = scale_values_any(g, transposed, dropout_p, seed, stream_id, g->deg,
+                          normalized == GNX_NORM_SYMMETRIC ? g->deg : nullptr, d_vals_out, stream);
     if (rc != GNX_OK) return rc;
     if (add_eye != GNX_EYE_NONE && n > 0) {
         const int mode = add_eye == GNX_EYE_AFTER ? 0 : (normalized == GNX_NORM_SYMMETRIC ? 1 : 2);
@@ -235,6 +269,18 @@ int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropou
     }
     GNX_HIP(hipGetLastError());
     return GNX_OK;
+}
+
+int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed, uint64_t stream_id,
+                        float *d_vals_out, float *d_diag_out, void *stream) {
+    return normalize_impl("gnx_graph_normalize", g, false, normalized, add_eye, dropout_p, seed, stream_id, d_vals_out,
+                          d_diag_out, stream);
+}
+
+int gnx_graph_normalize_t(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed, uint64_t stream_id,
+                          float *d_vals_t_out, float *d_diag_out, void *stream) {
+    return normalize_impl("gnx_graph_normalize_t", g, true, normalized, add_eye, dropout_p, seed, stream_id, d_vals_t_out,
+                          d_diag_out, stream);
 }
 
 }  // extern "C"

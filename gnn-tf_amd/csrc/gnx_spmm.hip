@@ -509,6 +509,36 @@ int gnx_spmm_t(gnx_graph_t g, const float *d_vals, const float *d_diag, const fl
     return launch_spmm(g, g->t, p, s);
 }
 
+int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_permute_values_t: NULL handle");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    if (g->a.nnz == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_vals_t_out != nullptr, "gnx_graph_permute_values_t: NULL output");
+    hipLaunchKernelGGL(k_gather_vals, dim3(blocks_for(g->a.nnz, 256)), dim3(256), 0, s, d_vals ? d_vals : g->raw_vals, g->t_perm,
+                       g->a.nnz, d_vals_t_out);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_spmm_tv(gnx_graph_t g, const float *d_vals_t, const float *d_diag, const float *d_X, int64_t ldx, int64_t C,
+                const float *d_H0, int64_t ldh0, float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm_tv", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_tv: invalid activation %d", act);
+    GNX_CHECK_ARG(d_diag == nullptr || g->a.n_rows == g->a.n_cols, "gnx_spmm_tv: diag needs a square graph");
+    GNX_CHECK_ARG(g->a.nnz == 0 || d_vals_t != nullptr, "gnx_spmm_tv: NULL values");
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    SpmmArgs p{};
+    p.vals = d_vals_t;
+    p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C;
+    return launch_spmm(g, g->t, p, s);
+}
+
 int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H, const float *d_H0, float a,
                  int64_t C, int act, float *d_out, void *stream) {
     GNX_CHECK_ARG(d_H0 != nullptr, "gnx_ppr_step: NULL H0");

@@ -27,6 +27,7 @@ SIGNATURES = {
     "gnx_graph_csr": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     "gnx_graph_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gnx_graph_normalize": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "gnx_graph_normalize_t": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "gnx_graph_colsum": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "gnx_degree_scale": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),
     "gnx_graph_scale_values": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -34,6 +35,9 @@ SIGNATURES = {
                          c_int, c_void_p, c_int64, c_void_p]),
     "gnx_spmm_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,
                            c_int, c_void_p, c_int64, c_void_p]),
+    "gnx_spmm_tv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,
+                            c_int, c_void_p, c_int64, c_void_p]),
+    "gnx_graph_permute_values_t": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "gnx_ppr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
     "gnx_appnp_propagate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p]),

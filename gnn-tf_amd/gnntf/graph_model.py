@@ -86,12 +86,12 @@ class PPRLoop(Layer):
         if self.graph_dropout != 0 and architecture.is_training():
             seed, first = architecture._next_mask_stream(self.iterations)
             graph, p = architecture.graph, self.graph_dropout
-            make_adj = lambda k: sparse.normalize(graph, "symmetric", "none", p, seed, first + k)
+            make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
         else:
             adj = architecture.get_adjacency(self.graph_dropout)
-            make_adj = lambda k: adj
+            make_adj = lambda k, bwd=False: adj
         if not torch.is_grad_enabled() and not (self.graph_dropout != 0 and architecture.is_training()):
-            return sparse.appnp_propagate(make_adj(0), self.H0.value, self.restart_probability, self.iterations)
+            return sparse.appnp_propagate(make_adj(0, False), self.H0.value, self.restart_probability, self.iterations)
         return sparse.ppr_loop(make_adj, self.H0.value, self.restart_probability, self.iterations)
 
 

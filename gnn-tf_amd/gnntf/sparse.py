@@ -116,29 +116,41 @@ class Adjacency:
     dropped-out) values + the diagonal weight of an added identity.  Usable with
     ``gnntf.spmm(adj, H)`` wherever the reference calls tf.sparse.sparse_dense_matmul."""
 
-    def __init__(self, graph: DeviceGraph, vals: torch.Tensor = None, diag: torch.Tensor = None):
+    def __init__(self, graph: DeviceGraph, vals: torch.Tensor = None, diag: torch.Tensor = None, vals_t: torch.Tensor = None):
         self.graph = graph
-        self.vals = vals
+        self.vals = vals          # values in coalesced-CSR order (None: the handle's raw values)
         self.diag = diag
+        self.vals_t = vals_t      # the same values in the order of the transposed structure (backward), or None
+
+    def transposed_values(self):
+        """Values in transposed order, permuted once and kept (a constant adjacency is reused by every backward)."""
+        if self.vals_t is None:
+            out = torch.empty(self.graph.nnz, dtype=torch.float32, device=self.graph.device)
+            with torch.cuda.device(self.graph.device):
+                nat.check(nat.lib().gnx_graph_permute_values_t(self.graph.handle, nat.ptr(self.vals), nat.ptr(out), nat.current_stream()))
+            self.vals_t = out
+        return self.vals_t
 
     @property
     def shape(self):
         return (self.graph.n_rows, self.graph.n_cols)
 
 
-def normalize(graph: DeviceGraph, normalized="symmetric", add_eye="none", dropout=0.0, seed=0, stream_id=0) -> Adjacency:
-    """GNN.get_adjacency on the device (reference gnn.py:36-50)."""
+def normalize(graph: DeviceGraph, normalized="symmetric", add_eye="none", dropout=0.0, seed=0, stream_id=0,
+              transposed_only=False) -> Adjacency:
+    """GNN.get_adjacency on the device (reference gnn.py:36-50).  ``transposed_only``: write the values in the
+    order of the transposed structure only (all a backward pass needs)."""
     if normalized not in nat.NORM:
         raise Exception("Invalid matrix normalization")
     if add_eye not in nat.EYE:
         raise Exception("Invalid add_eye option")
     vals = torch.empty(graph.nnz, dtype=torch.float32, device=graph.device)
     diag = torch.empty(graph.n_rows, dtype=torch.float32, device=graph.device) if add_eye != "none" else None
+    fn = nat.lib().gnx_graph_normalize_t if transposed_only else nat.lib().gnx_graph_normalize
     with torch.cuda.device(graph.device):
-        nat.check(nat.lib().gnx_graph_normalize(graph.handle, nat.NORM[normalized], nat.EYE[add_eye], float(dropout),
-                                                int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFFFFFFFFFF,
-                                                nat.ptr(vals), nat.ptr(diag), nat.current_stream()))
-    return Adjacency(graph, vals, diag)
+        nat.check(fn(graph.handle, nat.NORM[normalized], nat.EYE[add_eye], float(dropout), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                     int(stream_id) & 0xFFFFFFFFFFFFFFFF, nat.ptr(vals), nat.ptr(diag), nat.current_stream()))
+    return Adjacency(graph, None, diag, vals_t=vals) if transposed_only else Adjacency(graph, vals, diag)
 
 
 def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
@@ -168,9 +180,14 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None)
         H0 = _as_f32_rows(H0)
         if tuple(H0.shape) != (rows_out, C):
             raise Exception("spmm: H0 shape mismatch")
-    fn = nat.lib().gnx_spmm_t if transposed else nat.lib().gnx_spmm
+    if transposed:
+        fn, values = nat.lib().gnx_spmm_tv, adj.transposed_values()
+    else:
+        if adj.vals is None and adj.vals_t is not None:
+            raise Exception("spmm: this adjacency only holds transposed-order values")
+        fn, values = nat.lib().gnx_spmm, adj.vals
     with torch.cuda.device(X.device):
-        nat.check(fn(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
+        nat.check(fn(g.handle, nat.ptr(values), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
                      H0.stride(0) if H0 is not None else 0, float(beta), float(alpha), int(act), nat.ptr(out), out.stride(0),
                      nat.current_stream()))
     return out
@@ -219,7 +236,7 @@ class _PPRLoop(torch.autograd.Function):
         H0 = _as_f32_rows(H0).contiguous()
         H = H0
         for k in range(K):
-            H = _launch(make_adj(k), H, H0, 1.0 - a, a, nat.ACT_NONE)
+            H = _launch(make_adj(k, False), H, H0, 1.0 - a, a, nat.ACT_NONE)
         return H
 
     @staticmethod
@@ -228,14 +245,15 @@ class _PPRLoop(torch.autograd.Function):
         gH0 = torch.zeros_like(g)
         for k in range(ctx.K - 1, -1, -1):
             gH0.add_(g, alpha=ctx.a)
-            g = _launch(ctx.make_adj(k), g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
+            g = _launch(ctx.make_adj(k, True), g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
         gH0.add_(g)
         return gH0, None, None, None
 
 
 def ppr_loop(make_adj, H0: torch.Tensor, a: float, iterations: int) -> torch.Tensor:
-    """``iterations`` fused PPR steps starting from H0; ``make_adj(k)`` returns the Adjacency of
-    iteration k (called again, with the same k, during the backward)."""
+    """``iterations`` fused PPR steps starting from H0; ``make_adj(k, for_backward)`` returns the Adjacency
+    of iteration k (called again, with the same k and for_backward=True, during the backward, where only the
+    transposed-order values are needed)."""
     return _PPRLoop.apply(H0, make_adj, float(a), int(iterations))
 
 

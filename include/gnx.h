@@ -87,6 +87,13 @@ int gnx_graph_export(gnx_graph_t g, int64_t *d_rowptr_out, int32_t *d_colidx_out
 int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed,
                         uint64_t stream_id, float *d_vals_out, float *d_diag_out, void *stream);
 
+/* gnx_graph_normalize_t: the same normalisation, but the values are written in the order of the TRANSPOSED
+ * structure (the order gnx_spmm_tv consumes).  The backward pass of a training step only needs A_hat^T, so it
+ * regenerates the iteration's dropped adjacency straight into this order instead of permuting a CSR-order
+ * array (what tf.GradientTape keeps alive, trainable.py:70-78, is recomputed here from the counter RNG). */
+int gnx_graph_normalize_t(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed,
+                          uint64_t stream_id, float *d_vals_t_out, float *d_diag_out, void *stream);
+
 /* The three steps separately, for vertex-partitioned graphs where column sums need a
  * cross-rank all-reduce in between:
  *   colsum: d_colsum_out[j] = sum_i v_ij over this handle's rows (tf.sparse.reduce_sum
@@ -119,6 +126,14 @@ int gnx_spmm(gnx_graph_t g, const float *d_vals, const float *d_diag, const floa
 int gnx_spmm_t(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx,
                int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
                float *d_out, int64_t ldo, void *stream);
+
+/* gnx_spmm_tv: gnx_spmm_t with the values ALREADY in transposed order (from gnx_graph_normalize_t or
+ * gnx_graph_permute_values_t); skips the per-call permutation. */
+int gnx_spmm_tv(gnx_graph_t g, const float *d_vals_t, const float *d_diag, const float *d_X, int64_t ldx,
+                int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
+                float *d_out, int64_t ldo, void *stream);
+/* d_vals_t_out[p] = d_vals[perm[p]]: CSR-order values -> transposed order (for a constant adjacency). */
+int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream);
 
 /* One PPRIteration.__forward__ (filter.py:17-22) with a fixed adjacency:
  * out = act( (A_hat . H)*(1-a) + H0*a ).  Thin wrapper over gnx_spmm. */

@@ -307,6 +307,31 @@ def test_dropout_larger_graph(gnntf):
     assert set(np.unique(raw).tolist()) == {0.0, 2.0, 4.0}
 
 
+def test_transposed_order_values(gnntf):
+    """gnx_graph_normalize_t writes exactly the values gnx_graph_normalize writes, in the transposed structure's
+    order; gnx_spmm_tv on them == gnx_spmm_t on the CSR-order values (bitwise), with dropout and duplicates."""
+    from gnntf import _native as nat
+    from gnntf.sparse import _launch
+    lib = nat.lib()
+    coo, vals, shape = graphs.random_coo(300, 300, 5000, seed=41, weighted=True, dup_frac=0.3)
+    g = make_graph(gnntf, coo, vals, shape)
+    for p in (0.0, 0.5):
+        a_csr = gnntf.normalize(g, "symmetric", "after", dropout=p, seed=9, stream_id=4)
+        a_t = gnntf.normalize(g, "symmetric", "after", dropout=p, seed=9, stream_id=4, transposed_only=True)
+        assert torch.equal(a_csr.transposed_values(), a_t.vals_t) and torch.equal(a_csr.diag, a_t.diag)
+        G = dev(np.random.default_rng(1).standard_normal((300, 24)).astype(np.float32))
+        via_tv = _launch(a_t, G, None, 0.9, 0.0, 0, transposed=True)
+        out = torch.empty_like(G)
+        nat.check(lib.gnx_spmm_t(g.handle, nat.ptr(a_csr.vals), nat.ptr(a_csr.diag), nat.ptr(G), 24, 24, None, 0, 0.9, 0.0, 0,
+                                 nat.ptr(out), 24, nat.current_stream()))
+        assert torch.equal(out, via_tv)
+        ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=p, add_eye="after", training=p > 0, seed=9, stream=4, dtype=np.float64)
+        want = orc.sparse_dense_matmul(ai[:, ::-1], av, shape, G.cpu().numpy().astype(np.float64)) * 0.9
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    with pytest.raises(Exception, match="only holds transposed-order values"):
+        gnntf.spmm(a_t, G)
+
+
 @pytest.mark.parametrize("C", [7, 64])
 def test_backward_matches_oracle(gnntf, C):
     coo, vals, shape = graphs.random_coo(400, 400, 5000, seed=31, weighted=True)

@@ -11,7 +11,7 @@ g, adj, _ = bench.build_single(argparse.Namespace(nodes=10_000_000, entries=100_
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 H0 = (torch.rand(g.n_rows, C, device=dev) * 2 - 1).requires_grad_()
 gout = torch.rand(g.n_rows, C, device=dev)
-make = lambda k: gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=1, stream_id=k)
+make = lambda k, bwd=False: gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=1, stream_id=k, transposed_only=bwd)
 for it in range(3):
     H0.grad = None
     out = gnntf.ppr_loop(make, H0, 0.1, 10)
