@@ -433,7 +433,7 @@ int check_common(const char *fn, gnx_graph *g, const float *X, int64_t ldx, int6
     GNX_CHECK_ARG(g != nullptr, "%s: NULL handle", fn);
     GNX_CHECK_ARG(C >= 1 && C <= (1 << 20), "%s: feature width %lld not in [1, 2^20]", fn, (long long)C);
     GNX_CHECK_ARG(X != nullptr && out != nullptr, "%s: NULL X/out", fn);
-    GNX_CHECK_ARG(ldx >= C && ldo >= C && (H0 == nullptr || ldh0 >= C), "%s: leading dimension smaller than C", fn);
+    GNX_CHECK_ARG(ldx >= C && ldo >= C && (H0 == nullptr || ldh0 >= C || ldh0 == 0), "%s: leading dimension smaller than C", fn);
     GNX_CHECK_ARG((const void *)X != (const void *)out, "%s: out must not alias X", fn);
     return GNX_OK;
 }

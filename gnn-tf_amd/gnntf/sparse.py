@@ -176,10 +176,15 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None)
         out = torch.empty((rows_out, C), dtype=torch.float32, device=X.device)
     elif (tuple(out.shape) != (rows_out, C) or out.dtype != torch.float32 or out.stride(1) != 1 or not out.is_cuda):
         raise Exception("spmm: bad output buffer")
+    ldh0 = 0
     if H0 is not None:
         H0 = _as_f32_rows(H0)
-        if tuple(H0.shape) != (rows_out, C):
+        if tuple(H0.shape) == (1, C) and rows_out != 1:
+            H0, ldh0 = H0.contiguous(), 0                       # one row for every output row (bias)
+        elif tuple(H0.shape) != (rows_out, C):
             raise Exception("spmm: H0 shape mismatch")
+        else:
+            ldh0 = H0.stride(0)
     if transposed:
         fn, values = nat.lib().gnx_spmm_tv, adj.transposed_values()
     else:
@@ -188,7 +193,7 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None)
         fn, values = nat.lib().gnx_spmm, adj.vals
     with torch.cuda.device(X.device):
         nat.check(fn(g.handle, nat.ptr(values), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
-                     H0.stride(0) if H0 is not None else 0, float(beta), float(alpha), int(act), nat.ptr(out), out.stride(0),
+                     ldh0, float(beta), float(alpha), int(act), nat.ptr(out), out.stride(0),
                      nat.current_stream()))
     return out
 
@@ -255,6 +260,32 @@ def ppr_loop(make_adj, H0: torch.Tensor, a: float, iterations: int) -> torch.Ten
     of iteration k (called again, with the same k and for_backward=True, during the backward, where only the
     transposed-order values are needed)."""
     return _PPRLoop.apply(H0, make_adj, float(a), int(iterations))
+
+
+class _SpMMBiasAct(torch.autograd.Function):
+    """out = act(A . Y + bias) in one kernel (bias broadcast through the H0 operand, relu in the epilogue);
+    backward: g' = g * (out > 0), dY = A^T g', dbias = column sums of g'."""
+
+    @staticmethod
+    def forward(ctx, Y, bias, adj, relu):
+        out = _launch(adj, Y, bias, 1.0, 1.0, nat.ACT_RELU if relu else nat.ACT_NONE)
+        ctx.adj, ctx.relu, ctx.has_bias = adj, relu, bias is not None
+        ctx.save_for_backward(out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = (g * (out > 0)) if ctx.relu else g
+        g = g.contiguous()
+        gY = _launch(ctx.adj, g, None, 1.0, 0.0, nat.ACT_NONE, transposed=True) if ctx.needs_input_grad[0] else None
+        gb = g.sum(dim=0, keepdim=True) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gY, gb, None, None
+
+
+def spmm_bias_act(adj: Adjacency, Y: torch.Tensor, bias=None, relu=False) -> torch.Tensor:
+    """act(A . Y + bias) fused; ``bias`` is [1, C] or None."""
+    return _SpMMBiasAct.apply(Y, bias, adj, bool(relu))
 
 
 def spmm(adj: Adjacency, X: torch.Tensor) -> torch.Tensor:

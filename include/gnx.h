@@ -115,7 +115,8 @@ int gnx_graph_scale_values(gnx_graph_t g, float dropout_p, uint64_t seed, uint64
  *     beta = 1-a, alpha = a, the residual mix fused behind it (filter.py:20-21) and the
  *     optional activation (filter.py:22);
  *   - d_vals: values in coalesced-CSR order (from gnx_graph_normalize), NULL = raw values;
- *   - d_diag: per-row diagonal weight or NULL; d_H0 may be NULL (then alpha is ignored);
+ *   - d_diag: per-row diagonal weight or NULL; d_H0 may be NULL (then alpha is ignored); ldh0 == 0 broadcasts
+ *     ONE row of C values to every output row (a bias: gcn.py:89);
  *   - X is [n_cols, C], out and H0 are [n_rows, C]; out must not alias X.
  * gnx_spmm_t: the same with the transposed matrix (out is [n_cols, C], X and H0 index by
  *   the other side) -- the backward of gnx_spmm (what tf.GradientTape derives,

@@ -386,6 +386,31 @@ def test_golden_arxiv_gcn_layer_api(gnntf, golden_dir):
     assert (out >= 0).all()
 
 
+def test_gcn_transform_first(gnntf, golden_dir):
+    """GCN(transform_first=True): A.(X.W) with bias + relu in the SpMM epilogue == the reference order (A.X).W
+    within the float32 tolerance, forward and backward."""
+    z = np.load(os.path.join(golden_dir, "arxiv_mini_gcn.npz"))
+    coo, n = z["coo"].astype(np.int64), int(z["n"])
+    outs, grads = [], []
+    for tf_first in (False, True):
+        model = gnntf.GCN(gnntf.SparseCOO(coo, np.ones(len(coo), dtype=np.float32), (n, n)), z["X"].astype(np.float32), num_classes=40,
+                          transform_first=tf_first)
+        layers = model.layers()
+        assert [l.transform_first for l in layers] == [tf_first, tf_first]
+        layers[0].W.data.copy_(dev(z["W1"].astype(np.float32))); layers[0].b.data.copy_(dev(z["b1"].astype(np.float32)))
+        layers[1].W.data.copy_(dev(z["W2"].astype(np.float32))); layers[1].b.data.copy_(dev(z["b2"].astype(np.float32)))
+        model.training_mode(False)
+        out = model(model.features)
+        (out * dev(np.random.default_rng(0).standard_normal((n, 40)).astype(np.float32))).sum().backward()
+        outs.append(out.detach().cpu().numpy())
+        grads.append([layers[0].W.grad.cpu().numpy(), layers[0].b.grad.cpu().numpy(), layers[1].W.grad.cpu().numpy()])
+    np.testing.assert_allclose(outs[1], z["out32"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(outs[1], outs[0], rtol=RTOL, atol=ATOL)
+    for a, b in zip(*grads):
+        np.testing.assert_allclose(b, a, rtol=1e-3, atol=1e-3)
+    assert model.graph.last_kernel() in ("spmm_group16", "spmm_group32")
+
+
 def test_gcnii_layer_api(gnntf):
     """GCNII reuses the fused SpMM+mix kernel (gcn.py:7-27,54-74)."""
     coo, vals, shape = graphs.rmat_symmetric_coo(1500, 12000, seed=4)
