@@ -411,6 +411,31 @@ def test_gcn_transform_first(gnntf, golden_dir):
     assert model.graph.last_kernel() in ("spmm_group16", "spmm_group32")
 
 
+def test_model_level_degree_reorder(gnntf, golden_dir):
+    """GNN(reorder="degree"): same logits (float32 rounding) and the same labels in the caller's node order."""
+    from test_oracle_kat import load_cora
+    z, coo, vals, shape, X, weights = load_cora(golden_dir)
+    logits = []
+    for reorder in (None, "degree"):
+        model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, reorder=reorder)
+        for layer, (W, b) in zip([l for l in model.layers() if isinstance(l, gnntf.Dense)], weights):
+            layer.W.data.copy_(dev(W)); layer.b.data.copy_(dev(b))
+        model.training_mode(False)
+        with torch.no_grad():
+            logits.append(model(model.features).cpu().numpy())
+            again = model(dev(X)).cpu().numpy()                # features handed over in the caller's order
+        np.testing.assert_allclose(again, logits[-1], rtol=1e-6, atol=1e-7)
+        pred = model.predict(gnntf.NodeClassification(list(range(1708, 2708))))
+        assert pred.cpu().numpy().tolist() == z["argmax"][1708:].tolist()
+    np.testing.assert_allclose(logits[1], logits[0], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(logits[1], z["logits32"], rtol=RTOL, atol=1e-6)
+    # training still works end to end on the reordered model
+    labels = z["argmax"].astype(np.int64)
+    model.train(train=gnntf.NodeClassification(list(range(300)), labels[:300]), epochs=3, patience=3)
+    with pytest.raises(Exception, match="Invalid reorder option"):
+        gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, reorder="rcm")
+
+
 def test_gcnii_layer_api(gnntf):
     """GCNII reuses the fused SpMM+mix kernel (gcn.py:7-27,54-74)."""
     coo, vals, shape = graphs.rmat_symmetric_coo(1500, 12000, seed=4)

@@ -11,7 +11,9 @@ from gnntf.sparse import _launch
 from tools.bench_widths import timed
 
 dev = torch.device("cuda:0")
-a = argparse.Namespace(nodes=10_000_000, entries=100_000_000)
+mult = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+widths = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256, 32]
+a = argparse.Namespace(nodes=10_000_000 * mult, entries=100_000_000 * mult)
 g, adj, _ = bench.build_single(a, dev)
 n = g.n_rows
 rowptr, colidx, raw, rows = g.csr_arrays(with_rows=True)
@@ -26,7 +28,7 @@ for name, relabel in labelings.items():
         idx = torch.stack([relabel[rows.long()], relabel[colidx.long()]], 1)
         gg = gnntf.DeviceGraph(gnntf.SparseCOO(idx, raw, (n, n)), device=dev)
         aa = gnntf.normalize(gg, "symmetric")
-    for C in (256, 32):
+    for C in widths:
         H = torch.rand(n, C, device=dev); H0 = torch.rand(n, C, device=dev); out = torch.empty_like(H)
         ms = timed(lambda: _launch(aa, H, H0, 0.9, 0.1, 0, out=out), reps=5, warm=2)
         print(json.dumps({"labeling": name, "C": C, "ms": round(ms, 3), "kernel": gg.last_kernel()}))
