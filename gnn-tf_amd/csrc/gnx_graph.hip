@@ -146,6 +146,20 @@ __global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, 
     for (int64_t c = 0; c < nc; ++c) chunk_long[c0 + c] = p;
 }
 
+// key of a long-row chunk = the first column it touches: chunks are then processed in column-window order, so
+// that at any time the long-row waves gather from one window of columns and its hub rows stay cached
+__global__ void k_chunk_keys(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                             const int32_t *__restrict__ long_rows, const int64_t *__restrict__ long_chunk_ptr,
+                             const int32_t *__restrict__ chunk_long, int64_t n_chunks, uint32_t *__restrict__ keys,
+                             int32_t *__restrict__ ids) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int32_t li = chunk_long[c];
+    const int64_t beg = rowptr[long_rows[li]] + (c - long_chunk_ptr[li]) * LONG_CHUNK;
+    keys[c] = (uint32_t)colidx[beg];
+    ids[c] = (int32_t)c;
+}
+
 __global__ void k_make_tkeys(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ colidx, int64_t nnz,
                              int64_t n_rows, uint64_t *__restrict__ keys, int32_t *__restrict__ payload) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,6 +189,7 @@ void free_csr(Csr &m) {
     if (m.long_rows) (void)hipFree(m.long_rows);
     if (m.long_chunk_ptr) (void)hipFree(m.long_chunk_ptr);
     if (m.chunk_long) (void)hipFree(m.chunk_long);
+    if (m.chunk_order) (void)hipFree(m.chunk_order);
     if (m.row_order) (void)hipFree(m.row_order);
     m = Csr();
 }
@@ -230,6 +245,20 @@ int build_long_plan(Csr &m, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, pos.as<int32_t>(),
                        cpos.as<int64_t>(), m.long_rows, m.long_chunk_ptr, m.chunk_long);
     GNX_HIP(hipMemcpyAsync(m.long_chunk_ptr + m.n_long, &m.n_chunks, 8, hipMemcpyHostToDevice, s));
+    {   // column-window order of the chunks
+        DevBuf k0, k1, ids, t;
+        GNX_HIP(k0.alloc(m.n_chunks * 4)); GNX_HIP(k1.alloc(m.n_chunks * 4)); GNX_HIP(ids.alloc(m.n_chunks * 4));
+        GNX_HIP(hipMalloc((void **)&m.chunk_order, m.n_chunks * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_chunk_keys, dim3(blocks_for(m.n_chunks)), dim3(256), 0, s, m.rowptr, m.colidx, m.long_rows,
+                           m.long_chunk_ptr, m.chunk_long, m.n_chunks, k0.as<uint32_t>(), ids.as<int32_t>());
+        size_t tb = 0;
+        GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint32_t>(), k1.as<uint32_t>(), ids.as<int32_t>(), m.chunk_order,
+                                          (size_t)m.n_chunks, 0u, 32u, s));
+        GNX_HIP(t.alloc(tb));
+        GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint32_t>(), k1.as<uint32_t>(), ids.as<int32_t>(), m.chunk_order,
+                                          (size_t)m.n_chunks, 0u, 32u, s));
+        GNX_HIP(hipStreamSynchronize(s));
+    }
     GNX_HIP(hipStreamSynchronize(s));
     return GNX_OK;
 }

@@ -50,6 +50,7 @@ struct Csr {
     int32_t *long_rows = nullptr;       // [n_long] row ids
     int64_t *long_chunk_ptr = nullptr;  // [n_long+1] first chunk of each long row
     int32_t *chunk_long = nullptr;      // [n_chunks] index into long_rows
+    int32_t *chunk_order = nullptr;     // [n_chunks] chunk ids sorted by the first column they touch (see gnx_graph.hip)
     // rows in stable order of descending (clamped) entry count: the rows that share a wave in the
     // sub-wave kernels then have similar lengths (power-law graphs otherwise leave most lanes idle)
     int32_t *row_order = nullptr;       // [n_rows]
@@ -106,6 +107,7 @@ struct SpmmArgs {
     const int32_t *long_rows;
     const int64_t *long_chunk_ptr;
     const int32_t *chunk_long;
+    const int32_t *chunk_order;
     const int32_t *row_order;
     float *partial;
     int64_t n_long, n_chunks;

@@ -260,8 +260,9 @@ template <int VEC, int U>
 __global__ __launch_bounds__(256) void k_spmm_long_partial(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + wib;
-    if (chunk >= p.n_chunks) return;
+    const int64_t cslot = (int64_t)blockIdx.x * 4 + wib;
+    if (cslot >= p.n_chunks) return;
+    const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;   // column-window order
     const int32_t li = p.chunk_long[chunk];
     const int64_t row = p.long_rows[li];
     const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
@@ -285,8 +286,9 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_group(const SpmmArgs 
     constexpr int NS = 64 / G;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t chunk = (int64_t)blockIdx.x * 4 + wib;
-    if (chunk >= p.n_chunks) return;
+    const int64_t cslot = (int64_t)blockIdx.x * 4 + wib;
+    if (cslot >= p.n_chunks) return;
+    const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;   // column-window order
     const int32_t li = p.chunk_long[chunk];
     const int64_t row = p.long_rows[li];
     const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
@@ -448,6 +450,7 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
+    p.chunk_order = m.chunk_order;
     {
         static const int tune = [] { const char *e = getenv("GNX_TUNE"); return e ? atoi(e) : 0; }();
         p.tune = tune_override >= 0 ? tune_override : tune;
