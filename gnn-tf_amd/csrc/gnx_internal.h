@@ -37,8 +37,11 @@ void set_error(const char *fmt, ...);
 #ifndef GNX_LONG_ROW
 #define GNX_LONG_ROW 512
 #endif
+#ifndef GNX_LONG_CHUNK
+#define GNX_LONG_CHUNK GNX_LONG_ROW
+#endif
 constexpr int LONG_ROW = GNX_LONG_ROW;
-constexpr int LONG_CHUNK = GNX_LONG_ROW;
+constexpr int LONG_CHUNK = GNX_LONG_CHUNK;
 
 // One CSR-like structure (the matrix itself, or its transpose).
 struct Csr {
