@@ -8,7 +8,7 @@
 
 #include "../../include/gnx.h"
 
-#define GNX_VERSION_NUM 100 /* 0.1.0 */
+#define GNX_VERSION_NUM 101 /* 0.1.1 */
 
 namespace gnx {
 
