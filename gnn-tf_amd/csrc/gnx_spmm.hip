@@ -6,17 +6,20 @@
 // reference (gnntf/core/gnn/architectures/filter.py:19-22; gcn.py:88).
 //
 // The kernel is HBM-bound (2 flop per 4 gathered bytes), so the design is about memory
-// parallelism, not MFMA:
-//   * wide features (C >= 129 or any C the sub-wave path cannot hold): one 64-lane wave per
-//     row, each lane owning VEC contiguous columns, so every neighbour row is ONE coalesced
-//     wave-instruction (C = 256: 64 x float4 = the whole 1 KiB row).  The row's (col, val)
-//     pairs are fetched 64 at a time with one coalesced load and broadcast from registers
-//     with v_readlane, so the gather address is wave-uniform (SGPR base + lane offset), and
-//     U neighbour rows are kept in flight per wave before the first FMA;
-//   * narrow features: G = 4..32 lanes per row, 64/G rows per wave;
-//   * power-law rows: a row with more than LONG_ROW entries is cut into LONG_CHUNK-entry
-//     chunks summed by separate waves into a partial slab, then added in chunk order by a
-//     second kernel (fixed order: results are bitwise reproducible, no float atomics).
+// parallelism and cache behaviour, not MFMA:
+//   * wide features (more than 32 lanes of VEC columns, e.g. C = 256): one 64-lane wave per row, each
+//     lane owning VEC contiguous columns, so every neighbour row is ONE coalesced wave-instruction
+//     (C = 256: 64 x float4 = the whole 1 KiB row).  The row's (col, val) pairs are fetched 64 at a
+//     time with one coalesced load and broadcast from registers with v_readlane, and U = 8 neighbour
+//     rows are kept in flight per wave before the first FMA;
+//   * narrow features: G = 4..32 lanes per row, 64/G rows per wave, rows taken in a degree-binned
+//     order (Csr::row_order) so that the rows sharing a wave have similar lengths; for G <= 8 the next
+//     (col, val) batch is prefetched behind the gathers;
+//   * power-law rows: a row with more than LONG_ROW entries is cut into LONG_CHUNK-entry chunks summed
+//     by separate waves into a partial slab (wide: lanes across columns; narrow: sub-groups of lanes
+//     across the chunk's entries + a fixed xor tree), then added in chunk order by a second kernel
+//     (fixed order: results are bitwise reproducible, no float atomics).  Chunks are processed in
+//     column-window order (Csr::chunk_order) so the hub rows they share stay in L2 / Infinity Cache.
 #include <stdlib.h>
 
 #include "gnx_internal.h"
