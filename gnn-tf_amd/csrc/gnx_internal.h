@@ -104,6 +104,7 @@ struct SpmmArgs {
     int act;
     float *out;
     int64_t ldo;
+    const int32_t *out_rows;   // optional destination row of every result row (gnx_spmm_scatter)
     int64_t n_rows;
     int C;
     // long rows

@@ -156,8 +156,9 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = fmaxf(o[v], 0.f);
     }
-    if (nt) vstore_nt<VEC>(p.out + row * p.ldo + c, o);
-    else vstore<VEC>(p.out + row * p.ldo + c, o);
+    const int64_t orow = p.out_rows ? (int64_t)p.out_rows[row] : row;
+    if (nt) vstore_nt<VEC>(p.out + orow * p.ldo + c, o);
+    else vstore<VEC>(p.out + orow * p.ldo + c, o);
 }
 
 // ---- wide path: one wave per row -----------------------------------------------------------
@@ -513,6 +514,20 @@ int gnx_spmm_t(gnx_graph_t g, const float *d_vals, const float *d_diag, const fl
     p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
     p.out = d_out; p.ldo = ldo; p.C = (int)C;
     return launch_spmm(g, g->t, p, s);
+}
+
+int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx, int64_t C,
+                     const float *d_H0, int64_t ldh0, float beta, float alpha, int act, const int32_t *d_out_rows,
+                     float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm_scatter", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_scatter: invalid activation %d", act);
+    GNX_CHECK_ARG(d_diag == nullptr || g->a.n_rows == g->a.n_cols, "gnx_spmm_scatter: diag needs a square graph");
+    SpmmArgs p{};
+    p.vals = d_vals ? d_vals : g->raw_vals;
+    p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C; p.out_rows = d_out_rows;
+    return launch_spmm(g, g->a, p, (hipStream_t)stream);
 }
 
 int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream) {

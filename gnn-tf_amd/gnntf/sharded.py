@@ -68,8 +68,8 @@ class NativeBackend:
                                                        nat.ptr(out), nat.current_stream()))
         return out
 
-    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out):
-        sparse._launch(sparse.Adjacency(graph, vals), X, H0, beta, alpha, nat.ACT_NONE, out=out)
+    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out, out_rows=None):
+        sparse._launch(sparse.Adjacency(graph, vals), X, H0, beta, alpha, nat.ACT_NONE, out=out, out_rows=out_rows)
 
     def gather_rows(self, X, idx):
         return sparse.gather_rows(X, idx)
@@ -244,7 +244,7 @@ class ShardedGraph:
             rows = torch.repeat_interleave(torch.arange(self.n_local, device=dev), deg)
             g0 = be.graph_from_coo(torch.stack([newid[rows], newid[colidx.to(torch.int64)]], dim=1), nvals, (self.n_local, N))
             rowptr, colidx, nvals = be.csr_arrays(g0)
-            self.row_order, self.row_newid = order, newid
+            self.row_order, self.row_newid, self.row_order32 = order, newid, order.to(torch.int32)
             del rows, deg
         self.nnz_local = int(colidx.numel())
         t = torch.tensor([self.nnz_local], dtype=torch.int64, device=dev)
@@ -323,23 +323,26 @@ class ShardedGraph:
         state.cur = 1 - state.cur
 
     def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10):
-        """H <- H0, then K iterations; returns this rank's rows of the result."""
+        """H <- H0, then K iterations; returns this rank's rows of the result (in the caller's vertex order)."""
         state.cur = 0
-        if self.n_buf == self.n_local and iterations > 0:
-            # no halo (a single vertex block): the first iteration reads H0 in place instead of a copy of it
-            self.backend.spmm_mix(self.graph, None, state.H0, state.H0, 1.0 - a, a, state.bufs[1])
-            state.cur = 1
-            remaining = iterations - 1
-        else:
+        if self.n_buf != self.n_local or iterations == 0:              # halo present: the buffers carry [halo | local | halo]
             self.local_view(state.bufs[0]).copy_(state.H0)
-            remaining = iterations
-        for _ in range(remaining):
-            self.step(state, a)
-        out = self.local_view(state.bufs[state.cur])
-        if self.row_order is not None:                                 # back to the caller's vertex ids
-            torch.index_select(out, 0, self.row_newid, out=state.result)
-            return state.result
-        return out
+            for _ in range(iterations):
+                self.step(state, a)
+            return self.local_view(state.bufs[state.cur])
+        # a single vertex block: no exchange; the first iteration reads H0 in place, and on a relabelled shard
+        # the last one scatters its rows straight back into the caller's order
+        src = state.H0
+        for k in range(iterations):
+            last = k == iterations - 1
+            if last and self.row_order is not None:
+                self.backend.spmm_mix(self.graph, None, src, state.H0, 1.0 - a, a, state.result, out_rows=self.row_order32)
+                return state.result
+            dst = state.bufs[1 - state.cur]
+            self.backend.spmm_mix(self.graph, None, src, state.H0, 1.0 - a, a, dst)
+            state.cur = 1 - state.cur
+            src = dst
+        return src
 
     def halo_stats(self):
         t = torch.tensor([self.n_low + self.n_high, int(self.send_idx.numel()), self.n_local], dtype=torch.int64, device=self.device)

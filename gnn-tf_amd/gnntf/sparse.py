@@ -163,7 +163,7 @@ def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None):
+def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None, out_rows=None):
     g = adj.graph
     nat.require_cuda(X, H0)
     X = _as_f32_rows(X)
@@ -192,9 +192,16 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None)
             raise Exception("spmm: this adjacency only holds transposed-order values")
         fn, values = nat.lib().gnx_spmm, adj.vals
     with torch.cuda.device(X.device):
-        nat.check(fn(g.handle, nat.ptr(values), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
-                     ldh0, float(beta), float(alpha), int(act), nat.ptr(out), out.stride(0),
-                     nat.current_stream()))
+        if out_rows is not None:                                # result row i -> out[out_rows[i]]
+            if transposed or out_rows.dtype != torch.int32 or out_rows.numel() != rows_out or not out_rows.is_cuda:
+                raise Exception("spmm: bad output row map")
+            nat.check(nat.lib().gnx_spmm_scatter(g.handle, nat.ptr(values), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
+                                                 ldh0, float(beta), float(alpha), int(act), nat.ptr(out_rows), nat.ptr(out),
+                                                 out.stride(0), nat.current_stream()))
+        else:
+            nat.check(fn(g.handle, nat.ptr(values), nat.ptr(adj.diag), nat.ptr(X), X.stride(0), C, nat.ptr(H0),
+                         ldh0, float(beta), float(alpha), int(act), nat.ptr(out), out.stride(0),
+                         nat.current_stream()))
     return out
 
 

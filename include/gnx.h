@@ -136,6 +136,13 @@ int gnx_spmm_tv(gnx_graph_t g, const float *d_vals_t, const float *d_diag, const
 /* d_vals_t_out[p] = d_vals[perm[p]]: CSR-order values -> transposed order (for a constant adjacency). */
 int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream);
 
+/* gnx_spmm_scatter: gnx_spmm whose result row i is written to out[d_out_rows[i], :] (int32 [n_rows], a
+ * permutation).  Lets the LAST iteration of a propagation over a relabelled graph put the rows straight back
+ * into the caller's order instead of paying a separate un-permute pass. */
+int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx,
+                     int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
+                     const int32_t *d_out_rows, float *d_out, int64_t ldo, void *stream);
+
 /* One PPRIteration.__forward__ (filter.py:17-22) with a fixed adjacency:
  * out = act( (A_hat . H)*(1-a) + H0*a ).  Thin wrapper over gnx_spmm. */
 int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H,

@@ -49,9 +49,13 @@ class OracleBackend:
         rows = np.repeat(np.arange(g.n_rows), np.diff(g.rowptr))
         return torch.from_numpy(row_scale.numpy()[rows] * g.vals * col_scale.numpy()[g.colidx])
 
-    def spmm_mix(self, g, vals, X, H0, beta, alpha, out):
+    def spmm_mix(self, g, vals, X, H0, beta, alpha, out, out_rows=None):
         m = sp.csr_matrix((g.vals if vals is None else vals.numpy(), g.colidx, g.rowptr), shape=g.shape)
-        out.copy_(torch.from_numpy((m @ X.numpy()) * np.float32(beta) + H0.numpy() * np.float32(alpha)))
+        res = torch.from_numpy((m @ X.numpy()) * np.float32(beta) + H0.numpy() * np.float32(alpha))
+        if out_rows is None:
+            out.copy_(res)
+        else:
+            out[out_rows.long()] = res
 
     def gather_rows(self, X, idx):
         return X[idx].contiguous()

@@ -262,6 +262,23 @@ def test_closed_form_on_device(gnntf):
     np.testing.assert_allclose(gnntf.appnp_propagate(adj, dev(H0), 0.1, 10).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
 
 
+def test_scatter_output_rows(gnntf):
+    """gnx_spmm_scatter: result row i lands in out[perm[i]] (all dispatch classes incl. long rows)."""
+    from gnntf.sparse import _launch
+    coo, vals, shape = graphs.rmat_symmetric_coo(4000, 60000, seed=12)
+    adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape))
+    perm = torch.randperm(4000, device="cuda")
+    for C in (7, 32, 256):
+        X = dev(np.random.default_rng(C).standard_normal((4000, C)).astype(np.float32))
+        H0 = dev(np.random.default_rng(C + 1).standard_normal((4000, C)).astype(np.float32))
+        plain = _launch(adj, X, H0, 0.9, 0.1, 0)
+        out = torch.full_like(plain, float("nan"))
+        _launch(adj, X, H0, 0.9, 0.1, 0, out=out, out_rows=perm.to(torch.int32))
+        assert torch.equal(out[perm], plain)
+    with pytest.raises(Exception, match="bad output row map"):
+        _launch(adj, X, H0, 0.9, 0.1, 0, out=out, out_rows=perm)          # int64 map
+
+
 def test_strided_inputs_and_gather(gnntf):
     coo, vals, shape = graphs.rmat_symmetric_coo(1000, 8000, seed=8)
     adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape))
