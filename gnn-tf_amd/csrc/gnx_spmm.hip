@@ -163,11 +163,11 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
 
 // ---- wide path: one wave per row -----------------------------------------------------------
 // tune bits (GNX_TUNE, experiments): 1 = degree-binned row order, 2 = non-temporal H0/out, 4 = non-temporal col/val
-template <int VEC, int U, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_spmm_wave(const SpmmArgs p) {
+template <int VEC, int U, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t slot = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t slot = (int64_t)blockIdx.x * WPB + wib;
     if (slot >= p.n_rows) return;
     const int64_t row = (p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
@@ -403,7 +403,10 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
     if (lanes > 32) {
         // measured: U = 8 rows in flight is the plateau (U=4 +0.7 %, U=16 +17 %, forcing 8 waves/SIMD +14 %,
         // degree-ordered rows +9 %, non-temporal H0/out/index loads +-0 %)
-        GNX_LAUNCH((k_spmm_wave<VEC, 8, 1>), blocks_for(p.n_rows, 4), p);
+        // measured (tools/tune_spmm.py): 8 waves per block are 1.6 % faster than 4 when the row is one tile wide
+        // (C = 256), 0.6 % slower at two tiles (C = 512); 2 and 16 waves per block lose 3-11 %
+        if (p.C <= 64 * VEC) hipLaunchKernelGGL((k_spmm_wave<VEC, 8, 8>), dim3(blocks_for(p.n_rows, 8)), dim3(512), 0, s, p);
+        else                 hipLaunchKernelGGL((k_spmm_wave<VEC, 8, 4>), dim3(blocks_for(p.n_rows, 4)), dim3(256), 0, s, p);
         return "spmm_wave";
     }
     // measured (tools/tune_spmm.py, RMAT 10M/100M): prefetching the next (col, val) batch behind the
