@@ -272,8 +272,19 @@ int ensure_partial(gnx_graph *g, size_t bytes) {
     return GNX_OK;
 }
 
+static void drop_transpose(gnx_graph *g) {
+    free_csr(g->t);
+    if (g->t_perm) (void)hipFree(g->t_perm);
+    if (g->t_vals) (void)hipFree(g->t_vals);
+    if (g->t_raw) (void)hipFree(g->t_raw);
+    if (g->t_rowidx) (void)hipFree(g->t_rowidx);
+    g->t_perm = nullptr; g->t_vals = nullptr; g->t_raw = nullptr; g->t_rowidx = nullptr;
+    g->has_t = false;
+}
+
 int ensure_transpose(gnx_graph *g, hipStream_t s) {
     if (g->has_t) return GNX_OK;
+    struct Undo { gnx_graph *g; ~Undo() { if (g && !g->has_t) drop_transpose(g); } } undo{g};   // no half-built state on failure
     const Csr &a = g->a;
     Csr &t = g->t;
     t.n_rows = a.n_cols; t.n_cols = a.n_rows; t.nnz = a.nnz;
