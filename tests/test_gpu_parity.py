@@ -262,6 +262,30 @@ def test_closed_form_on_device(gnntf):
     np.testing.assert_allclose(gnntf.appnp_propagate(adj, dev(H0), 0.1, 10).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
 
 
+def test_handles_release_their_memory(gnntf):
+    """gnx_graph_destroy frees everything a handle allocated (CSR, transposed structure, plans, partial slab)."""
+    import gc
+    coo, vals, shape = graphs.rmat_symmetric_coo(20000, 400000, seed=6)
+    X = torch.rand(20000, 64, device="cuda")
+
+    def cycle():
+        g = make_graph(gnntf, coo, vals, shape)
+        adj = gnntf.normalize(g, "symmetric", "after", dropout=0.5, seed=1, stream_id=2)
+        out = gnntf.spmm(adj, X.requires_grad_())
+        out.sum().backward()                       # builds the transposed structure as well
+        del g, adj, out
+        gc.collect()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 * 2 ** 20, f"leaked {(free0 - free1) / 2 ** 20:.1f} MiB over 25 create/destroy cycles"
+
+
 def test_scatter_output_rows(gnntf):
     """gnx_spmm_scatter: result row i lands in out[perm[i]] (all dispatch classes incl. long rows)."""
     from gnntf.sparse import _launch
