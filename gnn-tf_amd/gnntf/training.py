@@ -1,9 +1,12 @@
-"""Predictor ABC and Trainable: cached full-graph forward, predict/loss/evaluate, and the
-full-batch training loop with L2 regularisation, early stopping and best-weights restore.
+"""Predictor ABC and Trainable: memoised full-graph forward and the full-batch training loop.
 
-Mirrors reference gnntf/core/nn/trainable.py:5-103 (same signatures and bookkeeping);
-tf.GradientTape + keras Adam become torch autograd + torch.optim.Adam (epsilon 1e-7 as in
-Keras).  The propagation layers inside the forward run on the HIP path.
+Behavioural contract: reference gnntf/core/nn/trainable.py:5-103 -- the ``train()`` signature, the
+objective (task loss + layer output penalties + L2 on regularised variables, scaled by
+``degradation(epoch)`` only inside the gradient), validation-loss early stopping with a patience
+counter that is re-armed on every improvement, and restoring the best variables at the end.
+The structure is this build's own: the epoch is three small pieces (``_Objective``, ``_BestSoFar``,
+``_fit_epoch``) around torch autograd + torch.optim.Adam (epsilon 1e-7, Keras's default, in place
+of tf.GradientTape + keras Adam).  The propagation layers inside the forward run on the HIP path.
 """
 from __future__ import annotations
 
@@ -15,6 +18,8 @@ from .protocol import Layered
 
 
 class Predictor(object):
+    """What a task exposes to an architecture (trainable.py:5-13)."""
+
     def predict(self, features):
         raise Exception("Predictors need to implement a predict method")
 
@@ -31,6 +36,56 @@ def _as_features(features):
     return torch.as_tensor(np.asarray(features), dtype=torch.float32).to(default_device())
 
 
+class _Objective:
+    """The scalar one optimisation step minimises (trainable.py:71-77): task loss on the training-mode
+    forward, plus ``layer.loss()`` of every layer with an output penalty, plus
+    ``regularization * var.regularize * sum(var^2)/2`` (= tf.nn.l2_loss) of every regularised variable."""
+
+    def __init__(self, model: "Trainable", task: Predictor, weight_decay: float):
+        self.model, self.task = model, task
+        self.penalised_layers = [layer for layer in model.layers() if layer.output_regularize != 0]
+        self.decayed = [(weight_decay * v.regularize, v.var) for v in model.vars() if v.regularize != 0]
+
+    def __call__(self):
+        total = self.task.loss(self.model(self.model.features))
+        for layer in self.penalised_layers:
+            total = total + layer.loss()
+        for coeff, tensor in self.decayed:
+            total = total + coeff * tensor.square().sum() / 2
+        return total
+
+
+class _BestSoFar:
+    """Early-stopping bookkeeping (trainable.py:60-62, 86, 96-102): the lowest validation loss seen, a
+    snapshot of every variable taken at that moment, and a countdown re-armed by each improvement."""
+
+    def __init__(self, variables, patience: int):
+        self.variables, self.patience = variables, patience
+        self.loss = float("inf")
+        self.snapshot = [v.identity() for v in variables]
+        self.countdown = patience
+
+    def observe(self, loss: float) -> bool:
+        """Consumes one epoch of patience; True when ``loss`` is a new minimum (snapshot refreshed)."""
+        self.countdown -= 1
+        if not loss < self.loss:
+            return False
+        self.loss = loss
+        self.snapshot = [v.identity() for v in self.variables]
+        return True
+
+    def rearm(self):
+        self.countdown = self.patience
+
+    @property
+    def exhausted(self) -> bool:
+        return self.countdown == 0
+
+    def restore(self):
+        for v, best in zip(self.variables, self.snapshot):
+            v.assign(best)
+
+
 class Trainable(Layered):
     def __init__(self, features):
         features = _as_features(features)
@@ -42,6 +97,7 @@ class Trainable(Layered):
         super().reset()
         self._fast_predict = None
 
+    # ---- memoised full-graph forward (trainable.py:26-39) --------------------------------------------
     def _cached_forward(self):
         if self._fast_predict is None:
             with torch.no_grad():
@@ -57,6 +113,27 @@ class Trainable(Layered):
     def evaluate(self, predictor: Predictor):
         return predictor.evaluate(self._cached_forward())
 
+    # ---- training ------------------------------------------------------------------------------------------
+    def _make_optimizer(self, optimizer, learning_rate):
+        params = [v.var for v in self.vars() if v.trainable]
+        if optimizer is None:
+            return torch.optim.Adam(params, lr=learning_rate, eps=1e-7)
+        if callable(optimizer) and not isinstance(optimizer, torch.optim.Optimizer):
+            return optimizer(params)           # a factory taking the parameter list
+        return optimizer
+
+    def _fit_epoch(self, objective: _Objective, optimizer, scale, batches: int) -> float:
+        """``batches`` full-batch steps in training mode; returns the summed (unscaled) objective."""
+        seen = 0.0
+        for _ in range(batches):
+            with self:                          # training mode on; the exit leaves eval mode (layered.py:37-42)
+                optimizer.zero_grad(set_to_none=True)
+                value = objective()
+                (value * scale).backward()
+                optimizer.step()
+            seen += float(value.detach())
+        return seen
+
     def train(self,
               train: Predictor,
               valid: Predictor = None,
@@ -70,49 +147,29 @@ class Trainable(Layered):
               batches: int = 1,
               optimizer=None):
         self.reset()
-        params = [var.var for var in self.vars() if var.trainable]
-        if optimizer is None:
-            optimizer = torch.optim.Adam(params, lr=learning_rate, eps=1e-7)
-        elif callable(optimizer) and not isinstance(optimizer, torch.optim.Optimizer):
-            optimizer = optimizer(params)
-        if valid is None:
-            valid = train
-        min_loss = float('inf')
-        min_loss_vars = [var.identity() for var in self.vars()]
-        patience_remaining = patience
+        optimizer = self._make_optimizer(optimizer, learning_rate)
+        judge = train if valid is None else valid
+        objective = _Objective(self, train, regularization)
+        best = _BestSoFar(self.vars(), patience)
         for epoch in range(epochs):
             self._fast_predict = None
-            loss = 0
-            for _ in range(batches):
-                with self as vars:
-                    optimizer.zero_grad(set_to_none=True)
-                    batch_loss = train.loss(self(self.features))
-                    for layer in self.layers():
-                        if layer.output_regularize != 0:
-                            batch_loss = batch_loss + layer.loss()
-                    for var in self.vars():
-                        if var.regularize != 0:
-                            batch_loss = batch_loss + regularization * var.regularize * (var.var ** 2).sum() / 2
-                    (batch_loss * degradation(epoch)).backward()
-                    optimizer.step()
-                    loss = loss + float(batch_loss.detach())
-
-            # patience mechanism (trainable.py:82-100); the exit of the `with` above left eval mode on
-            with torch.no_grad():
-                output = self(self.features)
-                valid_loss = float(valid.loss(output))
-            patience_remaining -= 1
-            if verbose and valid_loss < min_loss:
-                train_acc = float(train.evaluate(output))
-                test_acc = float("nan") if test is None else float(test.evaluate(output))
-                valid_acc = float(valid.evaluate(output))
-                print(f'\rEpoch {epoch}  patience {patience_remaining}  Train loss {float(loss):.3f} Validation loss {valid_loss:.3f}  Train {train_acc:.3f} Validation {valid_acc:.3f}  Test {test_acc:.3f}', end='')
-            if valid_loss < min_loss:
-                min_loss, min_loss_vars = valid_loss, [var.identity() for var in self.vars()]
-                patience_remaining = patience
-            if patience_remaining == 0:
+            fitted = self._fit_epoch(objective, optimizer, degradation(epoch), batches)
+            with torch.no_grad():               # eval-mode forward: validation decides (trainable.py:83-84)
+                logits = self(self.features)
+                held_out = float(judge.loss(logits))
+            if best.observe(held_out):
+                if verbose:
+                    self._report(epoch, best.countdown, fitted, held_out, logits, train, judge, test)
+                best.rearm()
+            if best.exhausted:
                 break
-        for var, best_var in zip(self.vars(), min_loss_vars):
-            var.assign(best_var)
+        best.restore()
         self._fast_predict = None
         print('\r')
+
+    @staticmethod
+    def _report(epoch, countdown, fitted, held_out, logits, train, judge, test):
+        scores = dict(train=float(train.evaluate(logits)), valid=float(judge.evaluate(logits)),
+                      test=float("nan") if test is None else float(test.evaluate(logits)))
+        print("\r[epoch %d | patience %d] loss: train %.3f, valid %.3f | acc: train %.3f, valid %.3f, test %.3f"
+              % (epoch, countdown, fitted, held_out, scores["train"], scores["valid"], scores["test"]), end='')
