@@ -4,26 +4,29 @@
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one K-iteration propagation H <- (1-a) A_hat H + a H0 (K = 10) over the resident
-synthetic graph, through the C ABI of libgnx.so.  N = 1: BASELINE.json configs[3], the roofline
-run (RMAT 10M nodes / 100M stored entries, 256 float32 features).  N > 1: the same generator with
-10M nodes / 100M entries PER GPU (weak scaling), 1-D vertex shards, halo rows exchanged over
-RCCL every iteration.  Prints ONE JSON line on rank 0.
+One "step" = one K-iteration propagation H <- (1-a) A_hat H + a H0 (K = 10) over the resident synthetic
+graph, through the C ABI of libgnx.so.  The workload is the SAME global graph for every N (strong scaling):
+BASELINE.json configs[4] -- RMAT 80M vertices / 1B stored entries, 128 float32 features -- on pv = N
+contiguous vertex blocks with a pairwise RCCL exchange of pulled rows / pushed partial sums per iteration
+(gnntf.sharded).  N = 1 is that graph on one GPU (it fits: ~131 GB) and additionally carries, in a
+``secondary`` block timed in the same run, BASELINE.json configs[3] (the roofline run, RMAT 10M / 100M,
+C = 256), other widths, config 3's arxiv-shaped GCN forward and a training-mode step.
+``--workload config4`` makes the roofline run the primary line instead.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd")]
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+WORKLOADS = {"config5": (80_000_000, 1_000_000_000, 128),       # BASELINE.json configs[4]: the scaling graph (default)
+             "config4": (10_000_000, 100_000_000, 256)}          # BASELINE.json configs[3]: the roofline run
 
 
 def parse():
@@ -31,60 +34,54 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nodes", type=int, default=10_000_000, help="vertices per GPU")
-    ap.add_argument("--entries", type=int, default=100_000_000, help="stored directed entries per GPU")
-    ap.add_argument("--feats", type=int, default=256)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["custom"], default="config5")
+    ap.add_argument("--nodes", type=int, default=None, help="vertices of the GLOBAL graph (implies --workload custom)")
+    ap.add_argument("--entries", type=int, default=None, help="stored directed entries of the GLOBAL graph")
+    ap.add_argument("--feats", type=int, default=None)
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--alpha", type=float, default=0.1)
-    ap.add_argument("--grid", type=str, default="", help="PVxPF process grid (vertex blocks x feature slices); default: chosen by gnntf.sharded.choose_grid")
+    ap.add_argument("--grid", type=str, default="", help="PVxPF process grid (vertex blocks x feature slices); default Nx1")
+    ap.add_argument("--cover", choices=["cover", "pull"], default="cover", help="halo plan: pull/push vertex cover or plain pull")
+    ap.add_argument("--chunks", type=int, default=2, help="column chunks whose exchange and SpMM overlap")
+    ap.add_argument("--whole-rows", action="store_true", help="do not split interior / boundary rows")
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the N = 1 line")
+    args = ap.parse_args()
+    if args.nodes or args.entries or args.feats:
+        base = WORKLOADS[args.workload if args.workload in WORKLOADS else "config5"]
+        args.nodes, args.entries, args.feats = args.nodes or base[0], args.entries or base[1], args.feats or base[2]
+        args.workload = "custom"
+    else:
+        args.nodes, args.entries, args.feats = WORKLOADS[args.workload]
+    return args
 
 
-# ---- synthetic graph --------------------------------------------
-def rmat_pairs(scale, m, gen, device, a=0.57, b=0.19, c=0.19):
-    src = torch.zeros(m, dtype=torch.int64, device=device)
-    dst = torch.zeros(m, dtype=torch.int64, device=device)
-    for _ in range(scale):
-        r = torch.rand(m, device=device, generator=gen)
-        src = src * 2 + (r >= a + b).long()
-        dst = dst * 2 + (((r >= a) & (r < a + b)) | (r >= a + b + c)).long()
-    return src, dst
+def alg_bytes_per_iteration(n, nnz, C):
+    """SURVEY.md section 8(d): nnz*(4 col + 4 val + 4C gathered row) + N*(4 rowptr + 4C H0 + 4C out)."""
+    return nnz * (8 + 4 * C) + n * (4 + 8 * C)
 
 
-def rmat_undirected_keys(n, m_undirected, seed, device):
-    """Exactly m_undirected distinct undirected edges {u < v} of an R-MAT graph relabelled onto n
-    vertices (ids folded by modulo, self loops dropped), as int64 keys u * n + v."""
-    gen = torch.Generator(device=device).manual_seed(seed)
-    scale = max(1, int(np.ceil(np.log2(n))))
-    keys = torch.empty(0, dtype=torch.int64, device=device)
-    while keys.numel() < m_undirected:
-        need = m_undirected - keys.numel()
-        s, d = rmat_pairs(scale, int(need * 1.25) + 1024, gen, device)
-        s, d = s % n, d % n
-        keep = s != d
-        s, d = s[keep], d[keep]
-        lo, hi = torch.minimum(s, d), torch.maximum(s, d)
-        keys = torch.unique(torch.cat([keys, lo * n + hi]))
-        del s, d, lo, hi, keep
-    if keys.numel() > m_undirected:
-        pick = torch.randperm(keys.numel(), device=device, generator=gen)[:m_undirected]
-        keys = keys[pick]
-    return keys
+def min_bytes_per_iteration(n, nnz, C):
+    """compulsory bytes, every array touched once: 8 nnz + 4 N + 12 N C."""
+    return 8 * nnz + 4 * n + 12 * n * C
 
 
+def workload_name(n, nnz, C):
+    return f"rmat_n{n}_nnz{nnz}_C{C}"
+
+
+# ---- synthetic graph (SURVEY.md section 8(d)) ---------------------------------------------------------
 def build_single(args, device):
+    """The whole graph on one GPU: R-MAT pairs -> symmetrised unsorted COO -> device CSR (A0) -> normalise once (A2)."""
+    import torch
     import gnntf
+    from gnntf import sharded
     n, m = args.nodes, args.entries // 2
     t0 = time.time()
-    keys = rmat_undirected_keys(n, m, seed=1, device=device)
-    gen = torch.Generator(device=device).manual_seed(3)
-    perm = torch.randperm(n, device=device, generator=gen)          # random vertex relabelling (seed 3)
-    u, v = perm[keys // n], perm[keys % n]
-    del keys
+    u, v = sharded.rmat_relabelled_pairs(n, m, seed=1, device=device)
     idx = torch.cat([torch.stack([u, v], 1), torch.stack([v, u], 1)])      # symmetrised COO, unsorted
-    del u, v, perm
+    del u, v
     vals = torch.ones(idx.shape[0], dtype=torch.float32, device=device)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
@@ -98,52 +95,204 @@ def build_single(args, device):
     return g, adj, dict(gen_s=round(t_gen, 2), prep_s=round(t_prep, 2))
 
 
-def alg_bytes_per_iteration(n, nnz, C):
-    """SURVEY.md section 8(d): nnz*(4 col + 4 val + 4C gathered row) + N*(4 rowptr + 4C H0 + 4C out)."""
-    return nnz * (8 + 4 * C) + n * (4 + 8 * C)
+def timed_steps(step, steps, warmup, barrier):
+    """W untimed steps, then exactly K timed ones bracketed by barrier + synchronize; also per-step events on the
+    launch stream.  Returns (wall seconds, [ms per step])."""
+    import torch
+    for _ in range(warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for s, e in ev:                     # events sit on the stream the kernels are launched on
+        s.record()
+        step()
+        e.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    return elapsed, [s.elapsed_time(e) for s, e in ev]
+
+
+def stream_copy_GBs(device, nbytes=4 << 30, reps=5):
+    """Device stream-copy rate (read + write bytes per second) measured in this run: the achievable HBM peak."""
+    import torch
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (s.elapsed_time(e) * 1e-3) / 1e9
+
+
+def pmc_traffic(name):
+    """Fabric (L2-miss) bytes per launch of this workload from the committed rocprofv3 PMC passes, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path)).get("workloads", {}).get(name)
+    if not rec:
+        return None, None
+    return float(rec["fabric_bytes_per_launch"]), f"profiles/pmc_traffic.json [{rec.get('source', '')}] -- builder-run rocprofv3 --pmc passes of this command, NOT measured in this run"
+
+
+def roofline_record(n, nnz, C, launch_s, K, name, measured_peak):
+    """achieved = min(B_alg, B_rocprof) / t per launch; B_alg, B_min, B_rocprof and t printed together."""
+    b_alg, b_min = alg_bytes_per_iteration(n, nnz, C), min_bytes_per_iteration(n, nnz, C)
+    traffic, source = pmc_traffic(name)
+    counted = min(b_alg, traffic) if traffic else b_alg
+    achieved = counted / launch_s / 1e9
+    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": source, "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
+           "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K, "alg_GBs": b_alg / launch_s / 1e9,
+           "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if measured_peak else None,
+           "note": "one launch = one fused SpMM+mix iteration incl. its long-row kernels; achieved = min(B_alg, traffic) / launch time; "
+                   "traffic = bytes leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE): Infinity-Cache hits are counted in it, so this is a "
+                   "fabric-level figure, not DRAM bandwidth; measured_peak = in-run device stream copy (read + write)"}
+    return rec
 
 
 # ---- CPU baseline: the oracle's C port on a bounded sample -------------------------------------------
 def cpu_baseline(g, H0, args):
+    import numpy as np
     import __graft_entry__ as ge
     lib = ctypes.CDLL(ge.build_oracle())
-    lib.oracle_sample_iteration.restype = ctypes.c_int
-    lib.oracle_sample_iteration.argtypes = [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64,
-                                                                                                      ctypes.c_void_p]
+    sig = [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    lib.oracle_sample_iteration_par.restype = ctypes.c_int
+    lib.oracle_sample_iteration_par.argtypes = sig
     lib.oracle_num_threads.restype = ctypes.c_int
     rowptr, colidx, vals = (t.cpu().numpy() for t in g.csr_arrays())
     H = H0.cpu().numpy()
     n, C = H.shape
     nnz = int(rowptr[-1])
 
-    def run(rows):
-        out = np.empty((rows, C), dtype=np.float32)
+    def run(rows, renorm=1):
+        out = np.empty((max(rows, 1), C), dtype=np.float32)
         t0 = time.time()
-        rc = lib.oracle_sample_iteration(n, rows, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, H.ctypes.data,
-                                         H.ctypes.data, args.alpha, C, out.ctypes.data)
+        rc = lib.oracle_sample_iteration_par(n, rows, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, H.ctypes.data,
+                                             H.ctypes.data, args.alpha, C, out.ctypes.data, renorm)
         assert rc == 0
         return time.time() - t0, int(rowptr[rows])
 
     probe_rows = min(n, 100_000)
-    t_probe, e_probe = run(probe_rows)
+    t_probe, e_probe = run(probe_rows, renorm=0)                   # SpMM + mix alone on a probe
     t_norm, _ = run(0)                                            # the whole-graph renormalisation alone
-    rate = max(e_probe, 1) / max(t_probe - t_norm, 1e-3)           # entries/s of the SpMM+mix part
-    rows = int(min(n, max(probe_rows, (args.cpu_seconds - t_norm) * rate / max(nnz / n, 1e-9))))
+    rate = max(e_probe, 1) / max(t_probe, 1e-3)
+    rows = int(min(n, max(probe_rows, max(args.cpu_seconds - t_norm, 1.0) * rate / max(nnz / n, 1e-9))))
     t, e = run(rows)
+    t_only, _ = run(rows, renorm=0)
     return {"value": e / t, "unit": "edges/s", "cores": int(lib.oracle_num_threads()), "kind": "port",
-            "sample": f"1 of {args.iterations} iterations over the first {rows} of {n} rows ({e} entries, C={C}) incl. the "
-                      f"per-iteration whole-graph renormalisation the reference does (gnn.py:36-50); {t:.1f} s; "
-                      f"CPU restatement of gnntf's TF-CPU path (TensorFlow unavailable)"}
+            "spmm_only_value": e / t_only,
+            "sample": f"1 of {args.iterations} iterations over the first {rows} of {n} rows ({e} entries, C={C}): value includes the "
+                      f"per-iteration whole-graph renormalisation the reference does (gnn.py:36-50 called from filter.py:18; "
+                      f"{t_norm:.1f} s of the {t:.1f} s, all threads), spmm_only_value is the same rows with the adjacency "
+                      f"normalised beforehand (what the GPU figure times; {t_only:.1f} s); CPU restatement of gnntf's TF-CPU path "
+                      f"(TensorFlow unavailable)"}
+
+
+# ---- secondary workloads (N = 1): timed in this same run so that they are driver-timed too ----------------
+def median_ms(fn, reps=5, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in evs)
+    return ms[len(ms) // 2]
+
+
+def secondary_workloads(args, device, measured_peak, skip_config4=False):
+    import torch
+    import gnntf
+    from gnntf import _native as nat
+    lib = nat.lib()
+    out = {}
+    K, a = args.iterations, args.alpha
+    n4, e4, c4 = WORKLOADS["config4"]
+    g, adj, prep = build_single(argparse.Namespace(nodes=n4, entries=e4), device)
+    n, nnz = g.n_rows, g.nnz
+    widths = []
+    for C in ([] if skip_config4 else [c4]) + [128, 64, 8]:
+        gen = torch.Generator(device=device).manual_seed(2)
+        H0 = torch.rand(n, C, device=device, generator=gen) * 2 - 1
+        res, work = torch.empty_like(H0), torch.empty_like(H0)
+        ms = median_ms(lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(res),
+                                                                 nat.ptr(work), nat.current_stream())), reps=3, warm=1)
+        rec = {"C": C, "kernel": g.last_kernel(), "ms_per_step": ms, "edges_per_s": nnz * K / ms * 1e3,
+               "roofline": roofline_record(n, nnz, C, ms * 1e-3 / K, K, workload_name(n4, e4, C), measured_peak)}
+        if C == c4:
+            out["config4_roofline_run"] = dict(rec, workload=workload_name(n4, e4, C) + f"_appnp_K{K}", prep=prep)
+        else:
+            widths.append(rec)
+        del H0, res, work
+    out["config4_graph_other_widths"] = widths
+    # training-mode step (SURVEY.md 8(f) rank 1): K = 10 iterations, each with its own dropped + re-normalised adjacency,
+    # forward + backward through the fused loop node (masks regenerated in the backward), C = 64
+    C = 64
+    H0 = (torch.rand(n, C, device=device) * 2 - 1).requires_grad_()
+    gout = torch.rand(n, C, device=device)
+    make = lambda k, bwd=False: gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=1, stream_id=k, transposed_only=bwd)
+
+    def train_step():
+        H0.grad = None
+        gnntf.ppr_loop(make, H0, a, K).backward(gout)
+    ms = median_ms(train_step, reps=3, warm=1)
+    out["training_step_C64"] = {"ms": ms, "what": f"forward + backward of {K} PPR iterations with per-iteration edge dropout 0.5 + "
+                                f"renormalisation, config-4 graph, C=64", "edges_per_s": 2 * nnz * K / ms * 1e3}
+    del H0, gout, g, adj
+    torch.cuda.empty_cache()
+    # config 3: arxiv-shaped 2-layer GCN forward (N = 169,343; 1,166,243 undirected pairs -> 2,332,486 stored entries; 128 -> 64 -> 40)
+    g3, adj3, _ = build_single(argparse.Namespace(nodes=169_343, entries=2_332_486), device)
+    X = torch.randn(g3.n_rows, 128, device=device)
+    model = gnntf.GCN(g3, X, num_classes=40)
+    model.training_mode(False)
+    with torch.no_grad():
+        t_fwd = median_ms(lambda: model(model.features), reps=20, warm=5)
+        X64 = torch.randn(g3.n_rows, 64, device=device)
+        t128 = median_ms(lambda: gnntf.spmm(adj3, X), reps=20, warm=5)
+        t64 = median_ms(lambda: gnntf.spmm(adj3, X64), reps=20, warm=5)
+    out["config3_arxiv_shaped_gcn"] = {"nodes": g3.n_rows, "entries": g3.nnz, "forward_ms": t_fwd, "spmm128_ms": t128, "spmm64_ms": t64,
+                                       "spmm128_edges_per_s": g3.nnz / t128 * 1e3, "spmm64_edges_per_s": g3.nnz / t64 * 1e3}
+    return out
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process group (nothing in this
+    process has touched the GPU yet) and relay its one JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(res.stdout)
+    raise SystemExit(res.returncode)
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
+    import torch
     # stdout carries exactly ONE JSON line: anything native libraries print there (RCCL's version banner)
     # is sent to stderr for the duration of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -153,7 +302,13 @@ def main():
     device = torch.device("cuda", local_rank)
     import gnntf
     gnntf.set_default_device(device)
+    K, C, a = args.iterations, args.feats, args.alpha
     sharded_path = world > 1 or args.force_sharded
+    pv, pf = world, 1
+    if args.grid:
+        pv, pf = (int(x) for x in args.grid.lower().split("x"))
+        if pv * pf != world or C % pf != 0:
+            raise SystemExit(f"bench.py: --grid {args.grid} needs PV * PF == {world} ranks and PF dividing the {C} features")
     if sharded_path:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
@@ -163,7 +318,6 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    K, C, a = args.iterations, args.feats, args.alpha
 
     if not sharded_path:
         g, adj, prep = build_single(args, device)
@@ -179,13 +333,12 @@ def main():
             nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(out), nat.ptr(work),
                                               nat.current_stream()))
         halo = None
+        C_local = C
     else:
         from gnntf import sharded
-        if args.grid:
-            grid = tuple(int(x) for x in args.grid.split("x"))
-        else:
-            grid = sharded.choose_grid(world, C, args.nodes * world, args.entries * world)
-        sg, prep, (gv, gf, pv, pf) = sharded.build_rmat_shard(args.nodes, args.entries, seed=1, device=device, grid=grid)
+        sg, prep, (gv, gf, pv, pf) = sharded.build_rmat_blocks(args.nodes, args.entries, seed=1, device=device, grid=(pv, pf),
+                                                              cover=args.cover, chunks=args.chunks, split_rows=not args.whole_rows,
+                                                              relabel=True)
         n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
         C_local = C // pf                                                       # this rank's feature slice
         gen = torch.Generator(device=device).manual_seed(2 + rank)
@@ -201,50 +354,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for s, e in ev:                     # events sit on the stream the kernels are launched on
-        s.record()
-        step()
-        e.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, step_ms = timed_steps(step, args.steps, args.warmup, barrier)
     if sharded_path:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    step_ms = [s.elapsed_time(e) for s, e in ev]
+        if world > 1:                        # measured, per iteration: the bare exchange and the bare kernels (collective calls)
+            t_x, t_c = sg.time_exchange(state), sg.time_compute(state, a)
+            halo_bytes = halo["max_halo_rows"] * C_local * 4
+            halo.update(exchange_ms_alone=t_x * 1e3, compute_ms_alone=t_c * 1e3, halo_bytes_per_rank_per_iteration=halo_bytes,
+                        ingress_GBs_per_rank=halo_bytes / max(t_x, 1e-9) / 1e9,
+                        GBs_per_link_and_direction=halo_bytes / max(t_x, 1e-9) / 1e9 / max(pv - 1, 1),
+                        pull_only_bytes_per_rank_per_iteration=halo["max_pull_only_rows"] * C_local * 4)
 
     if rank == 0:
         edges = nnz_global * K * args.steps
-        launch_s = (sum(step_ms) / len(step_ms)) / 1e3 / K          # one fused SpMM+mix launch (+ its long-row tail)
-        b_alg = alg_bytes_per_iteration(n_local, nnz_local, C_local if sharded_path else C)
-        achieved = b_alg / launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            rec = json.load(open(tpath))
-            if rec.get("workload") == f"rmat_n{args.nodes}_nnz{args.entries}_C{C}" and not sharded_path:
-                traffic = rec.get("hbm_bytes_per_launch")
+        measured_peak = stream_copy_GBs(device)
+        name = workload_name(args.nodes, args.entries, C)
+        if not sharded_path:
+            launch_s = (sum(step_ms) / len(step_ms)) / 1e3 / K      # one fused SpMM+mix launch (+ its long-row tail)
+            roof = roofline_record(n_local, nnz_local, C, launch_s, K, name, measured_peak)
+        else:                                                       # this rank's block: kernels alone (no exchange beside them)
+            t_c = sg.time_compute(state, a) if world == 1 else halo["compute_ms_alone"] * 1e-3
+            roof = roofline_record(n_local, nnz_local, C_local, t_c, K, name + f"_block_of_{pv}", measured_peak)
+            roof["note"] = "rank 0's vertex block, one iteration's kernels alone (pack + SpMM of every column chunk; no exchange beside them); " + roof["note"]
         result = {
-            "metric": "propagated edges/sec (APPNP K=10)", "value": edges / elapsed, "unit": "edges/s",
+            "metric": f"propagated edges/sec (APPNP K={K})", "value": edges / elapsed, "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"rmat_n{args.nodes}_nnz{args.entries}_C{C}_appnp_K{K}" + ("" if world == 1 else f"_per_gpu_x{world}"),
-                       "rows_per_rank": n_local, "stored_entries_per_rank": nnz_local, "stored_entries_total": nnz_global,
-                       "features": C, "iterations": K, "alpha": a, "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}_appnp_K{K}" + ("" if args.workload == "custom" else f" (BASELINE {args.workload})"),
+                       "global_rows": args.nodes, "stored_entries_total": nnz_global, "rows_per_rank": n_local,
+                       "stored_entries_per_rank": nnz_local, "features": C, "iterations": K, "alpha": a,
+                       "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (sg.graph.last_kernel() if sharded_path else g.last_kernel())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "alg_bytes_per_launch": b_alg, "launch_ms": launch_s * 1e3,
-                         "note": "one launch = one fused SpMM+mix iteration incl. its long-row kernels"},
+            "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:
             result["cpu_baseline"] = cpu_baseline(g, H0, args)
         else:
             result["cpu_baseline"] = None
+        if not sharded_path and not args.no_secondary:
+            del g, adj, H0, out, work
+            torch.cuda.empty_cache()
+            result["secondary"] = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4")
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if sharded_path:
         dist.barrier()

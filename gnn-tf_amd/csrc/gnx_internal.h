@@ -104,7 +104,8 @@ struct SpmmArgs {
     int act;
     float *out;
     int64_t ldo;
-    const int32_t *out_rows;   // optional destination row of every result row (gnx_spmm_scatter)
+    const int32_t *out_rows;   // optional destination row of every result row (gnx_spmm_scatter / gnx_spmm_rows)
+    bool map_h0;               // H0 rows are indexed through out_rows as well (gnx_spmm_rows)
     int64_t n_rows;
     int C;
     // long rows
@@ -119,6 +120,8 @@ struct SpmmArgs {
 };
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);
+#ifdef GNX_TUNING
 extern int tune_override;
+#endif
 
 }  // namespace gnx

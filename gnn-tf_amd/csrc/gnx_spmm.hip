@@ -142,10 +142,12 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
         for (int v = 0; v < VEC; ++v) acc[v] = fmaf(d, xr[v], acc[v]);
     }
     float o[VEC];
+    const int64_t orow = p.out_rows ? (int64_t)p.out_rows[row] : row;
     if (p.H0) {
+        const int64_t hrow = p.map_h0 ? orow : row;   // gnx_spmm_rows: H0 is indexed like the output
         float h0[VEC];
-        if (nt) vload_nt<VEC>(h0, p.H0 + row * p.ldh0 + c);
-        else vload<VEC>(h0, p.H0 + row * p.ldh0 + c);
+        if (nt) vload_nt<VEC>(h0, p.H0 + hrow * p.ldh0 + c);
+        else vload<VEC>(h0, p.H0 + hrow * p.ldh0 + c);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = acc[v] * p.beta + h0[v] * p.alpha;
     } else {
@@ -156,7 +158,6 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = fmaxf(o[v], 0.f);
     }
-    const int64_t orow = p.out_rows ? (int64_t)p.out_rows[row] : row;
     if (nt) vstore_nt<VEC>(p.out + orow * p.ldo + c, o);
     else vstore<VEC>(p.out + orow * p.ldo + c, o);
 }
@@ -451,17 +452,23 @@ int check_common(const char *fn, gnx_graph *g, const float *X, int64_t ldx, int6
 
 namespace gnx {
 
-int tune_override = -1;   // set through gnx_debug_set_tune (experiments only)
+#ifdef GNX_TUNING
+int tune_override = -1;   // set through gnx_debug_set_tune (tuning builds only: make TUNING=1)
+#endif
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
     p.chunk_order = m.chunk_order;
+#ifdef GNX_TUNING   // kernel-variant switches exist only in tuning builds (tools/tune_spmm.py); the product library has none
     {
         static const int tune = [] { const char *e = getenv("GNX_TUNE"); return e ? atoi(e) : 0; }();
         p.tune = tune_override >= 0 ? tune_override : tune;
     }
+#else
+    p.tune = 0;
+#endif
     p.n_long = m.n_long; p.n_chunks = m.n_chunks;
     p.partial = nullptr;
     if (m.n_rows == 0) return GNX_OK;
@@ -484,8 +491,10 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
 
 extern "C" {
 
-// not part of include/gnx.h: lets tools/tune_spmm.py flip kernel variants inside one process
+#ifdef GNX_TUNING
+// tuning builds only (make TUNING=1), not part of include/gnx.h: lets tools/tune_spmm.py flip kernel variants inside one process
 int gnx_debug_set_tune(int t) { tune_override = t; return 0; }
+#endif
 
 int gnx_spmm(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx, int64_t C,
              const float *d_H0, int64_t ldh0, float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream) {
@@ -530,6 +539,19 @@ int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, co
     p.vals = d_vals ? d_vals : g->raw_vals;
     p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
     p.out = d_out; p.ldo = ldo; p.C = (int)C; p.out_rows = d_out_rows;
+    return launch_spmm(g, g->a, p, (hipStream_t)stream);
+}
+
+int gnx_spmm_rows(gnx_graph_t g, const float *d_vals, const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0,
+                  float beta, float alpha, int act, const int32_t *d_rows, float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm_rows", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_rows: invalid activation %d", act);
+    GNX_CHECK_ARG(d_rows != nullptr || g->a.n_rows == 0, "gnx_spmm_rows: NULL row map");
+    SpmmArgs p{};
+    p.vals = d_vals ? d_vals : g->raw_vals;
+    p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C; p.out_rows = d_rows; p.map_h0 = true;
     return launch_spmm(g, g->a, p, (hipStream_t)stream);
 }
 

@@ -1,33 +1,44 @@
-"""Multi-GPU propagation (one process per GPU): a pv x pf grid of vertex blocks x feature slices.
+"""Multi-GPU propagation (one process per GPU): 1-D vertex blocks with a pairwise halo exchange per
+iteration, optionally crossed with feature slices (a pv x pf process grid).
 
-Feature columns propagate independently (the step acts on every column of H alike), so slicing the
-columns over ranks needs no exchange at all; vertex blocks need the halo exchange described below.
-choose_grid() picks the grid with a small measured cost model (grid_cost_ms).
+The reference has no distributed code at all; this module is the multi-GPU form of
+the same hot path -- PPRIteration.__forward__ (reference gnntf/core/gnn/architectures/filter.py:17-22)
+over a normalised adjacency (gnntf/core/gnn/gnn.py:36-50) -- and must give the same logits as one GPU.
 
-The reference has no distributed code at all; this module is the
-multi-GPU form of the same hot path -- PPRIteration.__forward__ (reference
-gnntf/core/gnn/architectures/filter.py:17-22) over a normalised adjacency
-(gnntf/core/gnn/gnn.py:36-50) -- and must give the same logits as one GPU.
+Rank r owns the global rows [lo, hi) of A_hat and the matching rows of H, H0 and the result.  For every
+entry (i, j) whose column lives on another rank q there are two ways to get its contribution:
 
-Layout per rank r owning the global rows [lo, hi):
-  * the rows of A_hat with all their entries (a local CSR);
-  * a feature buffer  X = [ halo_low | local rows | halo_high ]  where halo_low / halo_high
-    are the remote rows this rank's entries reference with global id < lo / >= hi, each sorted
-    by global id.  The column remap global -> buffer position is therefore MONOTONIC, so the
-    order of a row's entries -- and with it the floating-point summation order of the kernel --
-    is the same as on one GPU;
-  * per peer q a send list (which of my rows q needs).
-Each iteration: pack the send rows (gnx_gather_rows) -> pairwise isend/irecv of the halo rows
-(RCCL group of point-to-point transfers: every xGMI link carries its own peer's rows; no ring)
--> fused SpMM+mix over [X] writing the local part of the other ping-pong buffer.
+  pull   q sends the row H[j]; this rank multiplies it itself (the classic halo);
+  push   q, which holds H[j] anyway, sums  A_hat[i, j] * H[j]  over ITS columns j of row i and sends that
+         one partial-sum row; this rank only adds it (an entry of weight 1 on a "push slot" column).
 
-Column sums for the normalisation need one all-reduce of an N-vector at build time.
-The heavy lifting goes through a small backend object; the product backend is libgnx.so
-(NativeBackend).  Tests on CPU ranks (gloo) supply their own checker backend: this module
-never imports a CPU implementation.
+Either way one feature row crosses the link, so what the exchange costs is the size of a VERTEX COVER of the
+bipartite graph of cross entries between the two blocks: a pulled column covers all its entries, a pushed
+row covers all of its.  On power-law graphs the hubs on either side cover most entries: the cover is about
+half of the distinct remote columns a pull-only halo moves (``cover="pull"`` keeps the pull-only plan, whose
+per-row summation order -- and therefore every bit of the result -- equals the one-GPU kernel's).
+
+Layout per rank:
+  * X = [ region(0) .. region(r-1) | local rows | region(r+1) .. region(P-1) ],  region(q) = [ rows pulled
+    from q (ascending global id) | partial sums pushed by q ] -- one contiguous message per peer, and the
+    column remap of pulled rows stays MONOTONIC in the global id;
+  * the main CSR over X (interior rows -- no remote column -- and boundary rows as two handles when
+    ``split_rows``), values already normalised with GLOBAL column sums (gnn.py:41-42);
+  * a send CSR [rows to send x local rows]: a pulled row is a 1-entry row of weight 1, a pushed partial sum
+    a many-entry row, so ONE SpMM launch packs every outgoing message (no separate gather pass).
+
+Each iteration and column chunk: pack -> pairwise isend/irecv (RCCL group of point-to-point transfers:
+every xGMI link carries its own peer's rows; no ring) -> fused SpMM+mix.  Overlap comes from two sources:
+the feature columns are cut into ``chunks`` that propagate independently (filter.py:19-21 acts on every
+column alike), so the exchange of one chunk runs on its own stream under the SpMM of the other; and the
+interior rows of a chunk are computed before its halo is waited for.
+
+The heavy lifting goes through a small backend object; the product backend is libgnx.so (NativeBackend).
+Tests on CPU ranks (gloo) supply their own checker backend: this module never imports a CPU implementation.
 """
 from __future__ import annotations
 
+import contextlib
 import time
 
 import torch
@@ -46,8 +57,8 @@ class NativeBackend:
     def graph_from_csr(self, rowptr, colidx, vals, shape):
         return sparse.DeviceGraph(csr=(rowptr, colidx, vals, shape))
 
-    def csr_arrays(self, graph):
-        return graph.csr_arrays()
+    def csr_arrays(self, graph, with_rows=False):
+        return graph.csr_arrays(with_rows=with_rows)
 
     def colsum(self, graph):
         out = torch.empty(graph.n_cols, dtype=torch.float32, device=graph.device)
@@ -68,8 +79,17 @@ class NativeBackend:
                                                        nat.ptr(out), nat.current_stream()))
         return out
 
-    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out, out_rows=None):
-        sparse._launch(sparse.Adjacency(graph, vals), X, H0, beta, alpha, nat.ACT_NONE, out=out, out_rows=out_rows)
+    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out, out_rows=None, rows=None):
+        """out[i] = beta * (A X)[i] + alpha * H0[i];  ``rows``: the graph holds a subset of the output rows --
+        result row r belongs to out[rows[r]] / H0[rows[r]];  ``out_rows``: scatter of the result only."""
+        adj = sparse.Adjacency(graph, vals)
+        if rows is not None:
+            sparse.launch_rows(adj, X, H0, beta, alpha, rows, out)
+        else:
+            sparse._launch(adj, X, H0, beta, alpha, nat.ACT_NONE, out=out, out_rows=out_rows)
+
+    def spmm_plain(self, graph, X, out):
+        sparse._launch(sparse.Adjacency(graph, None), X, None, 1.0, 0.0, nat.ACT_NONE, out=out)
 
     def gather_rows(self, X, idx):
         return sparse.gather_rows(X, idx)
@@ -90,6 +110,9 @@ class Comm:
         # ranks on one card) stage through host memory.  RCCL groups never take this path.
         return t is not None and t.is_cuda and dist.get_backend(self.group) == "gloo"
 
+    def _global(self, q):
+        return q if self.group is None else dist.get_global_rank(self.group, q)
+
     def all_reduce(self, t, op=None):
         if self.size == 1:
             return t
@@ -100,6 +123,18 @@ class Comm:
             t.copy_(h)
         else:
             dist.all_reduce(t, op=op, group=self.group)
+        return t
+
+    def broadcast(self, t, src=0):
+        """In-place broadcast from group rank ``src``."""
+        if self.size == 1:
+            return t
+        if self._staged(t):
+            h = t.cpu()
+            dist.broadcast(h, self._global(src), group=self.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, self._global(src), group=self.group)
         return t
 
     def all_gather_vec(self, t):
@@ -113,7 +148,7 @@ class Comm:
     def exchange(self, send_chunks, recv_chunks):
         """Pairwise exchange: send_chunks[q] goes to group rank q, recv_chunks[q] is filled from it.
         One batch of point-to-point operations (NCCL/RCCL: a single group call, every peer pair on
-        its own xGMI link)."""
+        its own xGMI link).  Stream-ordered on the current stream for RCCL groups."""
         if self.size == 1:
             return
         if any(self._staged(t) for t in list(send_chunks) + list(recv_chunks)):
@@ -123,17 +158,28 @@ class Comm:
                 if q != self.rank and d is not None and d.numel() > 0:
                     d.copy_(h)
             return
-        peer = (lambda q: q) if self.group is None else (lambda q: dist.get_global_rank(self.group, q))
         ops = []
         for q, t in enumerate(recv_chunks):
             if q != self.rank and t is not None and t.numel() > 0:
-                ops.append(dist.P2POp(dist.irecv, t, peer(q), self.group))
+                ops.append(dist.P2POp(dist.irecv, t, self._global(q), self.group))
         for q, t in enumerate(send_chunks):
             if q != self.rank and t is not None and t.numel() > 0:
-                ops.append(dist.P2POp(dist.isend, t, peer(q), self.group))
+                ops.append(dist.P2POp(dist.isend, t, self._global(q), self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+
+    def alltoallv(self, chunks):
+        """chunks[q]: a 1-D tensor for group rank q (any length).  Returns what every rank sent to this one."""
+        if self.size == 1:
+            return [chunks[0]]
+        ref = chunks[0]
+        counts = torch.tensor([int(c.numel()) for c in chunks], dtype=torch.int64, device=ref.device)
+        table = self.all_gather_vec(counts)
+        recv = [torch.empty(int(table[q][self.rank]), dtype=ref.dtype, device=ref.device) for q in range(self.size)]
+        self.exchange([c.contiguous() for c in chunks], recv)
+        recv[self.rank] = chunks[self.rank]
+        return recv
 
 
 def make_grid(world, rank, pv, pf):
@@ -155,30 +201,33 @@ def make_grid(world, rank, pv, pf):
     return v, f, Comm(group=mine)
 
 
-def grid_cost_ms(pv, pf, feats, nodes_total, entries_total, link_GBs=60.0, halo_frac=0.16):
-    """Estimated time of ONE propagation iteration on a pv x pf grid, from round-1 measurements on MI355X:
+def grid_cost_ms(pv, pf, feats, nodes_total, entries_total, link_GBs, halo_frac=0.09):
+    """Estimated time of ONE propagation iteration on a pv x pf grid:
       * compute: entries per rank x (5.5 + 0.61 * max(w, 32)) ps, w = columns per rank -- the fused kernel's
         measured cost (RMAT 10M/100M: 2.5 / 4.5 / 8.6 / 16.3 ms at w = 32 / 64 / 128 / 256; below 32 columns a
         gather still moves one 128-byte line, so narrower slices are not cheaper);
       * exchange (pv > 1 only): halo_frac * nodes_total rows of 4w bytes arrive per rank over its pv - 1 links
-        (one xGMI link per peer, link_GBs per direction).  halo_frac = 0.16 is what a random 1-D partition of
-        the RMAT workload needs (tools/sim_grid.py: 12.4-14.5M rows of 80M); it is graph dependent."""
+        (one xGMI link per peer, ``link_GBs`` per direction -- a MEASURED figure: bench.py times a pairwise
+        exchange in-run and reports it; there is no built-in default).  halo_frac: cover rows per rank as a
+        share of all vertices (graph dependent; ShardedGraph.halo_stats() reports the real one);
+      * the two overlap (column chunks), so the iteration costs the larger of them."""
     w = max(feats // pf, 1)
     compute = entries_total / pv * (5.5 + 0.61 * max(w, 32)) * 1e-9
     comm = 0.0 if pv == 1 else halo_frac * nodes_total * 4.0 * w / ((pv - 1) * link_GBs * 1e9) * 1e3
-    return compute + comm
+    return max(compute, comm)
 
 
-def choose_grid(world, feats, nodes_total=80_000_000, entries_total=800_000_000, **model):
-    """Feature columns propagate independently (filter.py:19-21 acts on every column of H alike), so slicing
-    them over ranks needs NO exchange, while vertex blocks pay a halo exchange per iteration but keep rows
-    wide.  Picks the pv x pf factorisation of ``world`` (pf dividing ``feats``) with the lowest grid_cost_ms."""
+def choose_grid(world, feats, nodes_total, entries_total, link_GBs, **model):
+    """The pv x pf factorisation of ``world`` (pf dividing ``feats``) with the lowest grid_cost_ms for a measured
+    link rate.  bench.py does NOT use it for its headline number (that is always pv = world vertex blocks, the
+    grid BASELINE.json names); it is a planning helper: feature slices replicate the whole graph on every rank
+    (memory and prep grow with pf) and pay nothing per iteration, vertex blocks are the opposite."""
     best = None
     for pf in range(1, world + 1):
         if world % pf or feats % pf:
             continue
         pv = world // pf
-        cost = grid_cost_ms(pv, pf, feats, nodes_total, entries_total, **model)
+        cost = grid_cost_ms(pv, pf, feats, nodes_total, entries_total, link_GBs, **model)
         if best is None or cost < best[0] - 1e-12:
             best = (cost, pv, pf)
     return best[1], best[2]
@@ -188,25 +237,103 @@ def uniform_bounds(n_global, world):
     return [r * n_global // world for r in range(world + 1)]
 
 
-class ShardState:
-    """Ping-pong feature buffers of one propagation."""
+def split_columns(C, chunks):
+    """Column ranges of the ``chunks`` independent feature chunks (multiples of 32 columns = whole 128-byte
+    lines wherever the width allows, so every chunk keeps aligned float4 rows)."""
+    chunks = max(1, min(int(chunks), C))
+    unit = 32 if C % 32 == 0 and C // 32 >= chunks else (4 if C % 4 == 0 and C // 4 >= chunks else 1)
+    units = C // unit
+    cuts = [(units * k // chunks) * unit for k in range(chunks + 1)]
+    return [(cuts[k], cuts[k + 1]) for k in range(chunks) if cuts[k + 1] > cuts[k]]
 
-    def __init__(self, bufs, H0):
-        self.bufs, self.H0, self.cur = bufs, H0, 0
+
+def cover_push_mask(row, col, owner, rank, n_local, bnd):
+    """Which cross entries are PUSHED (summed by the column's owner) instead of pulled: a greedy vertex cover of
+    the cross entries between this block and each peer.  An entry (i, j), j owned by q, is first given to the
+    endpoint that covers more entries of that block pair (the column j if at least as many of this block's rows
+    reference it as row i has columns on q, else the row i); then every entry of a row that is pushed anyway
+    joins the push (free), which also frees the columns only such rows referenced.  A peer whose cover does not
+    come out smaller than its plain halo keeps the plain halo.
+    ``row`` local ids, ``col`` global ids, ``owner`` rank owning each column (all int64 [m]); ``bnd`` the upper
+    bounds of the P blocks.  Returns bool [m]."""
+    world, n_global = int(bnd.numel()), int(bnd[-1])
+    remote = owner != rank
+    push = torch.zeros_like(remote)
+    if world == 1 or not bool(remote.any()):
+        return push
+    dev = row.device
+    er, ec, eq = row[remote], col[remote], owner[remote]
+    kr = eq * n_local + er                                           # (peer, row) key
+    dr = torch.bincount(kr, minlength=world * n_local)               # entries of row i on peer q
+    dc = torch.bincount(ec, minlength=n_global)                      # rows of this block referencing column j
+    col_wins = dc[ec] >= dr[kr]
+    halo_per_peer = torch.bincount(torch.bucketize(torch.nonzero(dc).reshape(-1), bnd, right=True), minlength=world)
+    del dr, dc
+    pulled_col = torch.zeros(n_global, dtype=torch.bool, device=dev)
+    pulled_col[ec[col_wins]] = True
+    pushed_row = torch.zeros(world * n_local, dtype=torch.bool, device=dev)
+    pushed_row[kr[~pulled_col[ec]]] = True
+    pushed = pushed_row[kr]
+    # per peer: rows the cover moves (columns still pulled + rows pushed) against the plain halo
+    still = torch.zeros(n_global, dtype=torch.bool, device=dev)
+    still[ec[~pushed]] = True
+    cover_per_peer = torch.bincount(torch.bucketize(torch.nonzero(still).reshape(-1), bnd, right=True), minlength=world) \
+        + torch.bincount(torch.div(torch.nonzero(pushed_row).reshape(-1), max(n_local, 1), rounding_mode="floor"), minlength=world)
+    pushed &= (cover_per_peer < halo_per_peer)[eq]
+    push[remote] = pushed
+    return push
+
+
+class _Lanes:
+    """Two in-order lanes -- compute (the caller's stream) and exchange (a stream of its own) -- joined by
+    events.  On CPU ranks there are no streams and everything runs in program order."""
+
+    def __init__(self, device):
+        self.gpu = device.type == "cuda"
+        self.device = device
+        self._comm = torch.cuda.Stream(device) if self.gpu else None
+
+    def exchange_lane(self):
+        return torch.cuda.stream(self._comm) if self.gpu else contextlib.nullcontext()
+
+    def mark(self, on_exchange_lane=False):
+        if not self.gpu:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._comm if on_exchange_lane else torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait(self, ev, on_exchange_lane=False):
+        if ev is not None:
+            (self._comm if on_exchange_lane else torch.cuda.current_stream(self.device)).wait_event(ev)
+
+
+class ShardState:
+    """Buffers of one propagation: per column chunk two ping-pong [regions | local | regions] buffers and a
+    send buffer; H0 and the result hold this rank's rows at full width."""
+
+    def __init__(self, H0):
+        self.H0 = H0
+        self.cur = 0
 
 
 class ShardedGraph:
-    """This rank's shard of a symmetrically normalised, vertex-partitioned square graph."""
+    """This rank's block of a symmetrically normalised, vertex-partitioned square graph."""
 
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
-                 relabel=False):
-        """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this
-        rank owns (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.
-        Collective: every rank of the vertex partition (``comm`` / ``group``) must call it.
-        ``relabel`` (single vertex block only): store the shard with its vertices relabelled in stable order of
+                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False):
+        """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
+        (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.  Collective: every rank of the
+        vertex partition (``comm`` / ``group``) must call it with the same options.
+        ``cover``: "cover" (pull/push vertex cover, default) or "pull" (classic halo; bitwise the one-GPU sums).
+        ``split_rows``: interior rows (no remote column) as a handle of their own, computed before the halo is
+        waited for.  ``chunks``: independent column chunks whose exchange and SpMM overlap (default 2).
+        ``keep_entries``: keep (global row, global col, normalised value, pushed?) of this rank's entries in
+        ``self.entries`` (tests).  ``relabel`` (single vertex block only): store the shard with its vertices relabelled in stable order of
         descending entry count -- a legal preprocessing step that makes the sub-wave kernels
-        5-20 % faster (the rows a wave shares, their H0/out rows and the hub rows become neighbours in memory);
-        propagate() permutes H0 on the way in and the result on the way out, so callers never see the new ids."""
+        5-20 % faster; propagate() permutes H0 on the way in and the result on the way out."""
+        if cover not in ("cover", "pull"):
+            raise Exception("ShardedGraph: cover must be 'cover' or 'pull'")
         self.backend = backend if backend is not None else NativeBackend()
         self.comm = comm if comm is not None else Comm(group=group)
         self.group = self.comm.group
@@ -215,9 +342,12 @@ class ShardedGraph:
         dev = idx_global.device
         self.device = dev
         self.bounds = [int(b) for b in bounds]
+        if len(self.bounds) != self.world + 1:
+            raise Exception("ShardedGraph: bounds must list world + 1 boundaries")
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         N = self.bounds[-1]
         self.lo, self.hi, self.n_global, self.n_local = lo, hi, N, hi - lo
+        self.cover, self.chunks = cover, max(1, int(chunks))
         if idx_global.numel() and (int(idx_global[:, 0].min()) < lo or int(idx_global[:, 0].max()) >= hi):
             raise Exception("ShardedGraph: an entry's row is outside this rank's range [%d, %d)" % (lo, hi))
 
@@ -225,113 +355,244 @@ class ShardedGraph:
         local_idx = idx_global.clone()
         local_idx[:, 0] -= lo
         g0 = be.graph_from_coo(local_idx, vals, (self.n_local, N))
-        rowptr, colidx, raw = be.csr_arrays(g0)
+        del local_idx
+        rowptr, colidx, raw, rowidx = be.csr_arrays(g0, with_rows=True)
         if normalized == "symmetric":
             deg = be.colsum(g0)
             self.comm.all_reduce(deg)
             D = be.degree_scale(deg, "symmetric")
             nvals = be.scale_values(g0, D[lo:hi], D)
+            del deg, D
         elif normalized == "none":
             nvals = raw
         else:
             raise Exception("Invalid matrix normalization")
+        del g0, raw
         self.row_order = None
-        if relabel and self.world == 1 and colidx.numel() > 0:
+        self.nnz_local = int(colidx.numel())
+        t = torch.tensor([self.nnz_local], dtype=torch.int64, device=dev)
+        self.comm.all_reduce(t)
+        self.nnz_global = int(t.item())
+        self._lanes = _Lanes(dev)
+        self.entries = None
+        if keep_entries:
+            self.entries = [rowidx.to(torch.int64) + lo, colidx.to(torch.int64), nvals.clone(), None]
+
+        if self.world == 1:
+            self._build_single_block(rowptr, colidx, nvals, relabel)
+        else:
+            self._build_block(rowidx.to(torch.int64), colidx.to(torch.int64), nvals, split_rows)
+
+    # ---- one vertex block: no exchange -----------------------------------------------------------------
+    def _build_single_block(self, rowptr, colidx, nvals, relabel):
+        be, dev = self.backend, self.device
+        if relabel and colidx.numel() > 0:
             deg = rowptr[1:] - rowptr[:-1]
             order = torch.argsort(deg, descending=True, stable=True)                 # new id -> old id
             newid = torch.empty_like(order)
             newid[order] = torch.arange(order.numel(), device=dev)
             rows = torch.repeat_interleave(torch.arange(self.n_local, device=dev), deg)
-            g0 = be.graph_from_coo(torch.stack([newid[rows], newid[colidx.to(torch.int64)]], dim=1), nvals, (self.n_local, N))
-            rowptr, colidx, nvals = be.csr_arrays(g0)
+            g = be.graph_from_coo(torch.stack([newid[rows], newid[colidx.to(torch.int64)]], dim=1), nvals,
+                                  (self.n_local, self.n_global))
             self.row_order, self.row_newid, self.row_order32 = order, newid, order.to(torch.int32)
-            del rows, deg
-        self.nnz_local = int(colidx.numel())
-        t = torch.tensor([self.nnz_local], dtype=torch.int64, device=dev)
-        self.comm.all_reduce(t)
-        self.nnz_global = int(t.item())
+        else:
+            g = be.graph_from_csr(rowptr, colidx, nvals, (self.n_local, self.n_local))
+        self.graph = g
+        self.n_buf, self.n_before = self.n_local, 0
+        self.recv_counts, self.send_counts = [0], [0]
+        self.pull_counts, self.push_counts = [0], [0]
+        self.n_send = 0
+        self.stats = dict(pull_rows=0, push_rows=0, pull_only_rows=0, send_rows=0, interior_rows=self.n_local,
+                          boundary_rows=0, local_rows=self.n_local)
 
-        # halo plan: distinct remote columns, sorted by global id (=> grouped by owner)
-        col = colidx.to(torch.int64)
-        remote = (col < lo) | (col >= hi)
-        halo = torch.unique(col[remote])
-        self.halo_ids = halo                     # global ids of the halo rows: [low part | high part], ascending
-        n_low = int((halo < lo).sum())
-        self.n_low, self.n_high = n_low, int(halo.numel()) - n_low
-        pos = torch.searchsorted(halo, col)
-        new_col = torch.where(col < lo, pos, torch.where(col >= hi, pos + self.n_local, col - lo + n_low))
-        self.n_buf = self.n_low + self.n_local + self.n_high
-        self.graph = be.graph_from_csr(rowptr, new_col.to(torch.int32), nvals, (self.n_local, self.n_buf))
-        self.vals = None   # values live in the handle (raw values of the remapped CSR are already normalised)
-        del g0
-
-        # who owns which halo row; what every peer needs from me
+    # ---- a block among several: halo plan --------------------------------------------------------------
+    def _build_block(self, row, col, nvals, split_rows):
+        be, dev, comm = self.backend, self.device, self.comm
+        P, me, n_local, N, lo = self.world, self.rank, self.n_local, self.n_global, self.lo
         bnd = torch.tensor(self.bounds[1:], dtype=torch.int64, device=dev)
-        owner = torch.bucketize(halo, bnd, right=True)
-        recv_counts = torch.bincount(owner, minlength=self.world).to(torch.int64)
-        table = self.comm.all_gather_vec(recv_counts)
-        self.recv_counts = [int(c) for c in recv_counts.tolist()]
-        self.send_counts = [int(table[q][self.rank]) for q in range(self.world)]
-        roff = [0]
-        for c in self.recv_counts:
-            roff.append(roff[-1] + c)
-        want = [halo[roff[q]:roff[q + 1]].contiguous() for q in range(self.world)]      # ids I ask of q
-        asked = [torch.empty(self.send_counts[q], dtype=torch.int64, device=dev) for q in range(self.world)]
-        self.comm.exchange(want, asked)
-        self.send_idx = (torch.cat(asked) - lo) if sum(self.send_counts) else torch.empty(0, dtype=torch.int64, device=dev)
-        if self.send_idx.numel() and (int(self.send_idx.min()) < 0 or int(self.send_idx.max()) >= self.n_local):
+        owner = torch.bucketize(col, bnd, right=True)
+        remote = owner != me
+        push = cover_push_mask(row, col, owner, me, n_local, bnd) if self.cover == "cover" else torch.zeros_like(remote)
+        pull = remote & ~push
+        if self.entries is not None:
+            self.entries[3] = push.clone()
+        n_pull_only = int(torch.unique(col[remote]).numel())                     # what a pull-only halo would move
+
+        halo = torch.unique(col[pull])                                           # pulled global ids, ascending (= grouped by owner)
+        h_owner = torch.bucketize(halo, bnd, right=True)
+        pull_counts = torch.bincount(h_owner, minlength=P)
+        kpush = torch.unique(owner[push] * n_local + row[push])                  # pushed (peer, row) keys, ascending
+        p_owner = torch.div(kpush, max(n_local, 1), rounding_mode="floor")
+        push_counts = torch.bincount(p_owner, minlength=P)
+        recv_counts = pull_counts + push_counts
+        excl = lambda c: torch.cumsum(c, 0) - c
+        region_start = excl(recv_counts) + (torch.arange(P, device=dev) > me).to(torch.int64) * n_local
+        n_before = int(excl(recv_counts)[me])
+        self.n_before = n_before
+        self.n_buf = n_local + int(recv_counts.sum())
+        halo_col = region_start[h_owner] + torch.arange(halo.numel(), device=dev) - excl(pull_counts)[h_owner]
+        slot_col = region_start[p_owner] + pull_counts[p_owner] + torch.arange(kpush.numel(), device=dev) - excl(push_counts)[p_owner]
+        self.halo_ids = halo
+
+        # entries this rank multiplies itself: local + pulled columns, plus weight-1 entries on the push slots
+        keep = ~push
+        kcol = col[keep]
+        krow = row[keep]
+        klocal = ~remote[keep]
+        pos = torch.searchsorted(halo, kcol) if halo.numel() else torch.zeros_like(kcol)
+        pulled_col = halo_col[pos.clamp(max=max(halo.numel() - 1, 0))] if halo.numel() else torch.zeros_like(kcol)
+        new_col = torch.where(klocal, kcol - lo + n_before, pulled_col)
+        m_rows = torch.cat([krow, kpush % max(n_local, 1)])
+        m_cols = torch.cat([new_col, slot_col])
+        m_vals = torch.cat([nvals[keep], torch.ones(kpush.numel(), dtype=torch.float32, device=dev)])
+        is_bnd = torch.zeros(n_local, dtype=torch.bool, device=dev)
+        is_bnd[row[remote]] = True
+        del new_col, pulled_col, pos, kcol, krow, klocal, keep
+
+        # ---- tell every peer what to send: pulled ids + the entries of the rows it sums for me ---------------
+        push_slot = torch.searchsorted(kpush, owner[push] * n_local + row[push]) if kpush.numel() else torch.zeros(0, dtype=torch.int64, device=dev)
+        p_own_e = owner[push]
+        order = torch.argsort(p_own_e, stable=True)
+        e_slot = (push_slot - excl(push_counts)[p_own_e])[order]                 # slot inside the peer's push list
+        e_col = col[push][order]
+        e_val = nvals[push][order]
+        e_counts = torch.bincount(p_own_e, minlength=P)
+        e_off = [0] + torch.cumsum(e_counts, 0).tolist()
+        p_off = [0] + torch.cumsum(pull_counts, 0).tolist()
+        asked_ids = comm.alltoallv([halo[p_off[q]:p_off[q + 1]] for q in range(P)])
+        edges = comm.alltoallv([torch.stack([e_slot[e_off[q]:e_off[q + 1]], e_col[e_off[q]:e_off[q + 1]]], 1).reshape(-1)
+                                for q in range(P)])
+        evals = comm.alltoallv([e_val[e_off[q]:e_off[q + 1]] for q in range(P)])
+        table = comm.all_gather_vec(push_counts)                                 # table[g][q]: rows q pushes to g
+        del push_slot, p_own_e, order, e_slot, e_col, e_val, row, col, owner, remote, push, pull, nvals
+
+        self.pull_counts = [int(c) for c in pull_counts.tolist()]
+        self.push_counts = [int(c) for c in push_counts.tolist()]
+        self.recv_counts = [a + b for a, b in zip(self.pull_counts, self.push_counts)]
+        rs = region_start.tolist()
+        self.recv_slices = [(int(rs[q]), int(rs[q]) + self.recv_counts[q]) for q in range(P)]
+        s_rows, s_cols, s_vals, self.send_counts, self.send_slices = [], [], [], [], []
+        base = 0
+        for g in range(P):
+            a_g = 0 if g == me else int(asked_ids[g].numel())
+            b_g = 0 if g == me else int(table[g][me])
+            if g != me:
+                e = edges[g].reshape(-1, 2)
+                if b_g == 0 and e.shape[0] != 0 or (e.shape[0] and int(e[:, 0].max()) >= b_g):
+                    raise Exception("ShardedGraph: a peer's push plan is inconsistent")
+                s_rows += [base + torch.arange(a_g, device=dev), base + a_g + e[:, 0]]
+                s_cols += [asked_ids[g] - lo, e[:, 1] - lo]
+                s_vals += [torch.ones(a_g, dtype=torch.float32, device=dev), evals[g]]
+            self.send_counts.append(a_g + b_g)
+            self.send_slices.append((base, base + a_g + b_g))
+            base += a_g + b_g
+        self.n_send = base
+        s_rows = torch.cat(s_rows) if s_rows else torch.zeros(0, dtype=torch.int64, device=dev)
+        s_cols = torch.cat(s_cols) if s_cols else torch.zeros(0, dtype=torch.int64, device=dev)
+        s_vals = torch.cat(s_vals) if s_vals else torch.zeros(0, dtype=torch.float32, device=dev)
+        if s_cols.numel() and (int(s_cols.min()) < 0 or int(s_cols.max()) >= n_local):
             raise Exception("ShardedGraph: a peer asked for a row this rank does not own")
-        # where each peer's rows land in the buffer: low part for q < rank, high part for q > rank
-        self.recv_slices = []
-        for q in range(self.world):
-            start = roff[q] if q < self.rank else roff[q] + self.n_local
-            self.recv_slices.append((start, start + self.recv_counts[q]))
-        soff = [0]
-        for c in self.send_counts:
-            soff.append(soff[-1] + c)
-        self.send_slices = [(soff[q], soff[q + 1]) for q in range(self.world)]
+        self.send_graph = be.graph_from_coo(torch.stack([s_rows, s_cols], 1), s_vals, (self.n_send, n_local)) if self.n_send else None
+        del s_rows, s_cols, s_vals, asked_ids, edges, evals
+
+        # ---- the main CSR over X; interior rows (no remote column: their sums need no halo) apart -------------
+        n_bnd = int(is_bnd.sum())
+        self.split_rows = bool(split_rows) and 0 < n_bnd < n_local
+        if self.split_rows:
+            sel = is_bnd[m_rows]
+            rank_b = torch.cumsum(is_bnd.to(torch.int64), 0) - 1
+            rank_i = torch.cumsum((~is_bnd).to(torch.int64), 0) - 1
+            self.rows_bnd = torch.nonzero(is_bnd).reshape(-1).to(torch.int32)
+            self.rows_int = torch.nonzero(~is_bnd).reshape(-1).to(torch.int32)
+            self.graph = be.graph_from_coo(torch.stack([rank_b[m_rows[sel]], m_cols[sel]], 1), m_vals[sel], (n_bnd, self.n_buf))
+            self.graph_int = be.graph_from_coo(torch.stack([rank_i[m_rows[~sel]], m_cols[~sel]], 1), m_vals[~sel],
+                                               (n_local - n_bnd, self.n_buf))
+        else:
+            self.graph = be.graph_from_coo(torch.stack([m_rows, m_cols], 1), m_vals, (n_local, self.n_buf))
+            self.graph_int, self.rows_bnd, self.rows_int = None, None, None
+        self.stats = dict(pull_rows=sum(self.pull_counts), push_rows=sum(self.push_counts), pull_only_rows=n_pull_only,
+                          send_rows=self.n_send, interior_rows=n_local - n_bnd, boundary_rows=n_bnd, local_rows=n_local)
 
     # ---- propagation -----------------------------------------------------------------------------
     def local_view(self, buf):
-        return buf[self.n_low:self.n_low + self.n_local]
+        return buf[self.n_before:self.n_before + self.n_local]
 
-    def make_state(self, H0):
-        """Allocates the two [halo_low | local | halo_high] buffers for features of H0's width."""
+    def make_state(self, H0, chunks=None):
+        """Allocates the buffers for features of H0's width (this rank's rows)."""
         H0 = H0.to(torch.float32).contiguous()
         if H0.shape[0] != self.n_local:
             raise Exception("make_state: H0 must hold this rank's %d rows" % self.n_local)
-        bufs = [torch.zeros((self.n_buf, H0.shape[1]), dtype=torch.float32, device=H0.device) for _ in range(2)]
-        state = ShardState(bufs, H0)
-        if self.row_order is not None:                                 # relabelled shard: H0 in the new order, result buffer in the old
-            state.H0_user, state.H0 = H0, H0.index_select(0, self.row_order)
-            state.result = torch.empty_like(H0)
+        state = ShardState(H0)
+        C, dev = H0.shape[1], H0.device
+        if self.world == 1:
+            state.bufs = [torch.zeros((self.n_local, C), dtype=torch.float32, device=dev) for _ in range(2)]
+            if self.row_order is not None:                             # relabelled shard: H0 in the new order, result in the old
+                state.H0_user, state.H0 = H0, H0.index_select(0, self.row_order)
+                state.result = torch.empty_like(H0)
+            return state
+        state.cols = split_columns(C, self.chunks if chunks is None else chunks)
+        state.bufs = [[torch.zeros((self.n_buf, c1 - c0), dtype=torch.float32, device=dev) for _ in range(2)] for c0, c1 in state.cols]
+        state.send = [torch.zeros((max(self.n_send, 1), c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in state.cols]
+        state.result = torch.empty_like(H0)
         return state
 
-    def exchange_halo(self, buf):
-        """Fills the halo rows of ``buf`` with the owners' current local rows."""
-        local = self.local_view(buf)
-        packed = self.backend.gather_rows(local, self.send_idx) if self.send_idx.numel() else None
-        sends = [packed[a:b] if packed is not None and b > a else None for a, b in self.send_slices]
+    def _pack(self, state, c, buf):
+        """Every outgoing row of chunk c (pulled rows and pushed partial sums) from the local part of ``buf``."""
+        if self.send_graph is not None:
+            self.backend.spmm_plain(self.send_graph, self.local_view(buf), state.send[c][:self.n_send])
+
+    def _exchange(self, state, c, buf):
+        sends = [state.send[c][a:b] if b > a else None for a, b in self.send_slices]
         recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
         self.comm.exchange(sends, recvs)
 
-    def step(self, state: ShardState, a: float):
-        """One PPRIteration over the shard: halo exchange + fused SpMM/mix."""
-        cur, nxt = state.bufs[state.cur], state.bufs[1 - state.cur]
-        self.exchange_halo(cur)
-        self.backend.spmm_mix(self.graph, None, cur, state.H0, 1.0 - a, a, self.local_view(nxt))
-        state.cur = 1 - state.cur
+    def _compute(self, state, c, src, out, a, interior):
+        c0, c1 = state.cols[c]
+        H0 = state.H0[:, c0:c1]
+        if not self.split_rows:
+            if not interior:
+                self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out)
+        elif interior:
+            self.backend.spmm_mix(self.graph_int, None, src, H0, 1.0 - a, a, out, rows=self.rows_int)
+        else:
+            self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out, rows=self.rows_bnd)
 
     def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10):
         """H <- H0, then K iterations; returns this rank's rows of the result (in the caller's vertex order)."""
+        if self.world == 1:
+            return self._propagate_single_block(state, a, iterations)
+        if iterations == 0:
+            state.result.copy_(state.H0)
+            return state.result
+        lanes, nc = self._lanes, len(state.cols)
+        packed = []
+        for c, (c0, c1) in enumerate(state.cols):
+            self.local_view(state.bufs[c][0]).copy_(state.H0[:, c0:c1])
+            self._pack(state, c, state.bufs[c][0])
+            packed.append(lanes.mark())
+        for k in range(iterations):
+            last = k == iterations - 1
+            for c, (c0, c1) in enumerate(state.cols):
+                src, dst = state.bufs[c][k % 2], state.bufs[c][1 - k % 2]
+                with lanes.exchange_lane():                            # runs under the other chunk's SpMM
+                    lanes.wait(packed[c], on_exchange_lane=True)
+                    self._exchange(state, c, src)
+                    arrived = lanes.mark(on_exchange_lane=True)
+                out = state.result[:, c0:c1] if last else self.local_view(dst)
+                self._compute(state, c, src, out, a, interior=True)    # needs no halo
+                lanes.wait(arrived)
+                self._compute(state, c, src, out, a, interior=False)
+                if not last:
+                    self._pack(state, c, dst)
+                    packed[c] = lanes.mark()
+        return state.result
+
+    def _propagate_single_block(self, state, a, iterations):
+        # no exchange; the first iteration reads H0 in place, and on a relabelled shard the last one scatters its
+        # rows straight back into the caller's order
+        if iterations == 0:
+            return state.H0_user if self.row_order is not None else state.H0
         state.cur = 0
-        if self.n_buf != self.n_local or iterations == 0:              # halo present: the buffers carry [halo | local | halo]
-            self.local_view(state.bufs[0]).copy_(state.H0)
-            for _ in range(iterations):
-                self.step(state, a)
-            return self.local_view(state.bufs[state.cur])
-        # a single vertex block: no exchange; the first iteration reads H0 in place, and on a relabelled shard
-        # the last one scatters its rows straight back into the caller's order
         src = state.H0
         for k in range(iterations):
             last = k == iterations - 1
@@ -344,10 +605,62 @@ class ShardedGraph:
             src = dst
         return src
 
-    def halo_stats(self):
-        t = torch.tensor([self.n_low + self.n_high, int(self.send_idx.numel()), self.n_local], dtype=torch.int64, device=self.device)
+    # ---- measurements for bench.py ------------------------------------------------------------------------
+    def time_exchange(self, state, repeats=3):
+        """Seconds of one bare exchange of every chunk's outgoing rows (no compute beside it), max over ranks."""
+        if self.world == 1:
+            return 0.0
+        best = None
+        for _ in range(repeats + 1):
+            self._sync()
+            t0 = time.perf_counter()
+            for c in range(len(state.cols)):
+                self._exchange(state, c, state.bufs[c][0])
+            self._sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)          # the first round opens the connections
+        t = torch.tensor([best], dtype=torch.float64, device=self.device)
         self.comm.all_reduce(t, dist.ReduceOp.MAX)
-        return {"max_halo_rows": int(t[0]), "max_send_rows": int(t[1]), "max_local_rows": int(t[2])}
+        return float(t.item())
+
+    def time_compute(self, state, a=0.1, repeats=3):
+        """Seconds of one iteration's kernels alone (pack + SpMM of every chunk, no exchange), max over ranks."""
+        best = None
+        for _ in range(repeats + 1):
+            self._sync()
+            t0 = time.perf_counter()
+            if self.world == 1:
+                self.backend.spmm_mix(self.graph, None, state.H0, state.H0, 1.0 - a, a, state.bufs[1])
+            else:
+                for c in range(len(state.cols)):
+                    src, dst = state.bufs[c][0], state.bufs[c][1]
+                    self._compute(state, c, src, self.local_view(dst), a, interior=True)
+                    self._compute(state, c, src, self.local_view(dst), a, interior=False)
+                    self._pack(state, c, dst)
+            self._sync()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        t = torch.tensor([best], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce(t, dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def _sync(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+    def halo_stats(self):
+        """Max over ranks of the plan sizes (rows): what crosses the links per iteration and how the rows split."""
+        keys = ["pull_rows", "push_rows", "pull_only_rows", "send_rows", "interior_rows", "boundary_rows", "local_rows"]
+        t = torch.tensor([self.stats[k] for k in keys], dtype=torch.int64, device=self.device)
+        self.comm.all_reduce(t, dist.ReduceOp.MAX)
+        out = {"max_" + k: int(v) for k, v in zip(keys, t.tolist())}
+        t = torch.tensor([self.stats["pull_rows"] + self.stats["push_rows"]], dtype=torch.int64, device=self.device)
+        self.comm.all_reduce(t, dist.ReduceOp.MAX)
+        out["max_halo_rows"] = int(t.item())
+        out["cover"], out["split_rows"], out["chunks"] = self.cover, bool(getattr(self, "split_rows", False)), self.chunks
+        return out
 
 
 # ---- synthetic sharded R-MAT (bench.py, N > 1) ------------------------------------------------------------
@@ -361,11 +674,80 @@ def _rmat_pairs(scale, m, gen, device, a=0.57, b=0.19, c=0.19):
     return src, dst
 
 
-def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=None, group=None, grid=None, relabel=True):
-    """Weak-scaling workload: a global R-MAT graph with nodes_per_rank * P vertices and about
-    entries_per_rank * P stored (symmetrised, de-duplicated) entries, on a pv x pf process grid
-    (default: pv = P vertex blocks, one feature slice).  Every rank draws its share of undirected edges;
-    the shares are all-gathered so that every rank sees the same global edge set, the same global vertex
+def rmat_undirected_keys(n, m_undirected, seed, device):
+    """Exactly m_undirected distinct undirected edges {u < v} of an R-MAT graph (a, b, c, d) = (0.57, 0.19, 0.19,
+    0.05) folded onto n vertices (ids modulo n, self loops dropped), as int64 keys u * n + v."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    scale = max(1, (n - 1).bit_length())
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    while keys.numel() < m_undirected:
+        need = m_undirected - keys.numel()
+        s, d = _rmat_pairs(scale, int(need * 1.25) + 1024, gen, device)
+        s, d = s % n, d % n
+        keep = s != d
+        s, d = s[keep], d[keep]
+        lo, hi = torch.minimum(s, d), torch.maximum(s, d)
+        del s, d, keep
+        keys = torch.unique(torch.cat([keys, lo * n + hi]))
+        del lo, hi
+    if keys.numel() > m_undirected:
+        pick = torch.randperm(keys.numel(), device=device, generator=gen)[:m_undirected]
+        keys = keys[pick]
+    return keys
+
+
+def rmat_relabelled_pairs(n, m_undirected, seed, device, perm_seed=3):
+    """The bench graph: rmat_undirected_keys + a random vertex relabelling (so locality is not an artefact of the
+    generator).  Returns (u, v) int64 [m_undirected] each; the stored matrix is the symmetrised pattern."""
+    keys = rmat_undirected_keys(n, m_undirected, seed, device)
+    gen = torch.Generator(device=device).manual_seed(perm_seed)
+    perm = torch.randperm(n, device=device, generator=gen)
+    u, v = perm[torch.div(keys, n, rounding_mode="floor")], perm[keys % n]
+    return u, v
+
+
+def build_rmat_blocks(n_global, entries_global, seed, device, backend=None, group=None, grid=None, **graph_options):
+    """STRONG-scaling workload: ONE global R-MAT graph (n_global vertices, entries_global stored entries -- the
+    same graph for every world size, and the graph bench.py's one-GPU run builds) cut into pv contiguous vertex
+    blocks.  Rank 0 generates the edge list and broadcasts it; every rank keeps the entries of its rows.
+    Returns (ShardedGraph, info, (v, f, pv, pf))."""
+    world_comm = Comm(group=group) if dist.is_initialized() else Comm(solo=True)
+    rank, world = world_comm.rank, world_comm.size
+    pv, pf = grid if grid is not None else (world, 1)
+    v, f, comm = make_grid(world, rank, pv, pf)
+    t0 = time.time()
+    m = entries_global // 2
+    if rank == 0:
+        u, w = rmat_relabelled_pairs(n_global, m, seed, device)
+        pairs = torch.stack([u, w])
+        del u, w
+    else:
+        pairs = torch.empty((2, m), dtype=torch.int64, device=device)
+    world_comm.broadcast(pairs, 0)
+    u, w = pairs[0], pairs[1]
+    bounds = uniform_bounds(n_global, pv)
+    lo, hi = bounds[v], bounds[v + 1]
+    mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
+    idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
+    del u, w, mu, mw, pairs
+    vals = torch.ones(idx.shape[0], dtype=torch.float32, device=device)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    sg = ShardedGraph(idx, vals, bounds, backend=backend, comm=comm, **graph_options)
+    del idx, vals
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+        torch.cuda.empty_cache()
+    return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2)), (v, f, pv, pf)
+
+
+def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=None, group=None, grid=None, relabel=True,
+                     **graph_options):
+    """WEAK-scaling variant (kept for rehearsals and tests): a global R-MAT graph with nodes_per_rank * P vertices
+    and about entries_per_rank * P stored entries on a pv x pf grid.  Every rank draws its share of undirected
+    edges; the shares are exchanged so that every rank sees the same global edge set, the same global vertex
     permutation is applied, and each rank keeps the rows of its vertex block.
     Returns (ShardedGraph, info, (v, f, pv, pf))."""
     world_comm = Comm(group=group) if dist.is_initialized() else Comm(solo=True)
@@ -384,21 +766,13 @@ def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=Non
     keys = torch.unique(torch.minimum(s, d) * N + torch.maximum(s, d))
     del s, d, keep
     # every rank receives every share (identical global edge set on all ranks)
-    counts = world_comm.all_gather_vec(torch.tensor([keys.numel()], dtype=torch.int64, device=device))
-    recvs = [keys if q == rank else torch.empty(int(counts[q]), dtype=torch.int64, device=device) for q in range(world)]
-    world_comm.exchange([keys] * world, recvs)
-    keys = torch.unique(torch.cat(recvs))                      # de-duplicate across shares
-    del recvs
+    keys = torch.unique(torch.cat(world_comm.alltoallv([keys] * world)))     # de-duplicate across shares
     pgen = torch.Generator(device=device).manual_seed(3)
     perm = torch.randperm(N, device=device, generator=pgen)
-    if world > 1:                                              # the SAME permutation everywhere: rank 0's
-        if world_comm._staged(perm):
-            h = perm.cpu(); dist.broadcast(h, 0, group=group); perm.copy_(h)
-        else:
-            dist.broadcast(perm, 0, group=group)
+    world_comm.broadcast(perm, 0)                              # the SAME permutation everywhere: rank 0's
     bounds = uniform_bounds(N, pv)
     lo, hi = bounds[v], bounds[v + 1]
-    u, w = perm[keys // N], perm[keys % N]
+    u, w = perm[torch.div(keys, N, rounding_mode="floor")], perm[keys % N]
     del keys, perm
     mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
     idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
@@ -408,7 +782,7 @@ def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=Non
         torch.cuda.synchronize(device)
     t_gen = time.time() - t0
     t0 = time.time()
-    sg = ShardedGraph(idx, vals, bounds, backend=backend, comm=comm, relabel=relabel)
+    sg = ShardedGraph(idx, vals, bounds, backend=backend, comm=comm, relabel=relabel, **graph_options)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2)), (v, f, pv, pf)

@@ -205,6 +205,32 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
     return out
 
 
+def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out):
+    """The fused step over a graph that holds a SUBSET of the output rows (the interior or the boundary rows of
+    a vertex block): result row r is written to out[rows[r]] and mixes in H0[rows[r]] (gnx_spmm_rows)."""
+    g = adj.graph
+    nat.require_cuda(X, H0, rows, out)
+    X = _as_f32_rows(X)
+    if X.shape[0] != g.n_cols:
+        raise Exception(f"spmm: features have {X.shape[0]} rows, adjacency expects {g.n_cols}")
+    C = X.shape[1]
+    if rows.dtype != torch.int32 or rows.numel() != g.n_rows or not rows.is_contiguous():
+        raise Exception("spmm: bad row map")
+    if out.dtype != torch.float32 or out.dim() != 2 or out.shape[1] != C or out.stride(1) != 1:
+        raise Exception("spmm: bad output buffer")
+    ldh0 = 0
+    if H0 is not None:
+        H0 = _as_f32_rows(H0)
+        if tuple(H0.shape) != tuple(out.shape):
+            raise Exception("spmm: H0 shape mismatch")
+        ldh0 = H0.stride(0)
+    with torch.cuda.device(X.device):
+        nat.check(nat.lib().gnx_spmm_rows(g.handle, nat.ptr(adj.vals), nat.ptr(X), X.stride(0), C, nat.ptr(H0), ldh0, float(beta),
+                                          float(alpha), nat.ACT_NONE, nat.ptr(rows), nat.ptr(out), out.stride(0),
+                                          nat.current_stream()))
+    return out
+
+
 class _SpMM(torch.autograd.Function):
     """out = A . X ; backward dX = A^T . g (what tf.GradientTape derives for filter.py:19)."""
 

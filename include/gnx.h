@@ -13,8 +13,10 @@
  *     which synchronise that stream (they read sizes back to size their allocations);
  *   - return value: 0 = ok, < 0 = error code below; gnx_last_error() then holds a
  *     thread-local message.  Nothing throws across this boundary;
- *   - a gnx_graph_t owns its device-side index arrays (hipMalloc) until gnx_graph_destroy;
- *     it is not re-entrant: use one handle from one stream at a time;
+ *   - a gnx_graph_t owns its device-side index arrays (hipMalloc) until gnx_graph_destroy.
+ *     ONE STREAM PER HANDLE AT A TIME: a handle keeps per-handle scratch (the long-row partial slab, which is
+ *     re-allocated when a wider C arrives, the transposed-value and degree scratch), so two streams or threads
+ *     launching on the same handle concurrently race on it.  Different handles are independent;
  *   - features are row-major float32, leading dimension (`ld*`, in elements) given per call.
  */
 #ifndef GNX_H
@@ -142,6 +144,14 @@ int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals
 int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_X, int64_t ldx,
                      int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
                      const int32_t *d_out_rows, float *d_out, int64_t ldo, void *stream);
+
+/* gnx_spmm_rows: the fused step for a handle that holds only a SUBSET of the output rows (the interior or the
+ * boundary rows of a vertex block, compacted): result row r lands in out[d_rows[r], :] and mixes in
+ * H0[d_rows[r], :] (d_rows int32 [n_rows of the handle]; out and H0 are the full-height matrices).  Same
+ * arithmetic per row as gnx_spmm (filter.py:19-21); no diagonal term. */
+int gnx_spmm_rows(gnx_graph_t g, const float *d_vals, const float *d_X, int64_t ldx, int64_t C, const float *d_H0,
+                  int64_t ldh0, float beta, float alpha, int act, const int32_t *d_rows, float *d_out, int64_t ldo,
+                  void *stream);
 
 /* One PPRIteration.__forward__ (filter.py:17-22) with a fixed adjacency:
  * out = act( (A_hat . H)*(1-a) + H0*a ).  Thin wrapper over gnx_spmm. */

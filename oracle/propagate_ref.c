@@ -86,6 +86,49 @@ int oracle_sample_iteration(int64_t n, int64_t n_sample, const int64_t *rowptr, 
     return 0;
 }
 
+/* The same normalisation with every pass spread over the OpenMP threads (column sums through atomic adds, so the
+ * float summation order -- and the last bits -- vary from run to run).  Only bench.py's cpu_baseline uses it:
+ * it lets the CPU figure renormalise per iteration like the reference without a single-threaded pass inside. */
+void oracle_normalize_symmetric_par(int64_t n, const int64_t *rowptr, const int32_t *colidx,
+                                    const float *vals, float *vals_out, float *colsum /* [n] scratch */) {
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) colsum[j] = 0.0f;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+#pragma omp atomic
+            colsum[colidx[e]] += vals[e];
+        }
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < n; ++j) {
+        float s = sqrtf(colsum[j]);
+        colsum[j] = (s != 0.0f) ? 1.0f / s : 0.0f;
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e)
+            vals_out[e] = colsum[i] * vals[e] * colsum[colidx[e]];
+}
+
+/* oracle_sample_iteration with the parallel normalisation; renorm == 0 skips the normalisation and treats
+ * raw_vals as A_hat's values (the SpMM + mix alone, which is what the GPU figure times). */
+int oracle_sample_iteration_par(int64_t n, int64_t n_sample, const int64_t *rowptr, const int32_t *colidx,
+                                const float *raw_vals, const float *H, const float *H0, float a, int64_t C,
+                                float *out /* [n_sample, C] */, int renorm) {
+    if (!renorm) {
+        oracle_ppr_step(n_sample, rowptr, colidx, raw_vals, H, H0, a, C, out);
+        return 0;
+    }
+    const int64_t nnz = rowptr[n];
+    float *nv = (float *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+    float *cs = (float *)malloc((size_t)(n > 0 ? n : 1) * sizeof(float));
+    if (!nv || !cs) { free(nv); free(cs); return -1; }
+    oracle_normalize_symmetric_par(n, rowptr, colidx, raw_vals, nv, cs);
+    oracle_ppr_step(n_sample, rowptr, colidx, nv, H, H0, a, C, out);
+    free(nv); free(cs);
+    return 0;
+}
+
 /* K iterations, renormalising each time like the reference.  `out` and `work` are [n, C];
  * the result lands in `out`.  Returns 0, or -1 on allocation failure. */
 int oracle_appnp_propagate(int64_t n, const int64_t *rowptr, const int32_t *colidx,

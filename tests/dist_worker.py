@@ -1,6 +1,9 @@
 """Worker of tests/test_sharded_cpu.py: one gloo rank of the vertex-partitioned propagation.
 The checker backend below stands in for libgnx.so on CPU ranks (tests may use the oracle; the
-product backend is gnntf.sharded.NativeBackend)."""
+product backend is gnntf.sharded.NativeBackend).
+
+    dist_worker.py MODE [cpu|cuda] [cover|pull],[split|whole],CHUNKS
+"""
 import os
 import sys
 
@@ -28,13 +31,16 @@ class _G:
 
 class OracleBackend:
     def graph_from_coo(self, idx, vals, shape):
-        return _G(*orc.coo_to_csr_coalesced(idx.numpy(), vals.numpy(), shape), shape)
+        return _G(*orc.coo_to_csr_coalesced(idx.numpy().reshape(-1, 2), vals.numpy(), shape), shape)
 
     def graph_from_csr(self, rowptr, colidx, vals, shape):
         return _G(rowptr.numpy(), colidx.numpy(), vals.numpy(), shape)
 
-    def csr_arrays(self, g):
-        return torch.from_numpy(g.rowptr), torch.from_numpy(g.colidx), torch.from_numpy(g.vals)
+    def csr_arrays(self, g, with_rows=False):
+        out = (torch.from_numpy(g.rowptr), torch.from_numpy(g.colidx), torch.from_numpy(g.vals))
+        if with_rows:
+            out += (torch.from_numpy(np.repeat(np.arange(g.n_rows), np.diff(g.rowptr)).astype(np.int32)),)
+        return out
 
     def colsum(self, g):
         out = np.zeros(g.n_cols, dtype=np.float32)
@@ -49,13 +55,24 @@ class OracleBackend:
         rows = np.repeat(np.arange(g.n_rows), np.diff(g.rowptr))
         return torch.from_numpy(row_scale.numpy()[rows] * g.vals * col_scale.numpy()[g.colidx])
 
-    def spmm_mix(self, g, vals, X, H0, beta, alpha, out, out_rows=None):
+    def _product(self, g, vals, X):
         m = sp.csr_matrix((g.vals if vals is None else vals.numpy(), g.colidx, g.rowptr), shape=g.shape)
-        res = torch.from_numpy((m @ X.numpy()) * np.float32(beta) + H0.numpy() * np.float32(alpha))
+        return m @ X.numpy()
+
+    def spmm_mix(self, g, vals, X, H0, beta, alpha, out, out_rows=None, rows=None):
+        prod = self._product(g, vals, X) * np.float32(beta)
+        if rows is not None:
+            r = rows.long()
+            out[r] = torch.from_numpy(prod) + H0[r] * np.float32(alpha)
+            return
+        res = torch.from_numpy(prod + H0.numpy() * np.float32(alpha))
         if out_rows is None:
             out.copy_(res)
         else:
             out[out_rows.long()] = res
+
+    def spmm_plain(self, g, X, out):
+        out.copy_(torch.from_numpy(self._product(g, None, X)))
 
     def gather_rows(self, X, idx):
         return X[idx].contiguous()
@@ -66,6 +83,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     mode = sys.argv[1]
     on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"          # GPU box: every rank shares cuda:0, libgnx.so backend
+    opts = (sys.argv[3] if len(sys.argv) > 3 else "cover,split,2").split(",")
+    options = dict(cover=opts[0], split_rows=opts[1] == "split", chunks=int(opts[2]), keep_entries=True)
     dev = torch.device("cuda:0" if on_gpu else "cpu")
     backend = None if on_gpu else OracleBackend()
     C, K, a = (64 if on_gpu else 12), 10, 0.1
@@ -78,12 +97,27 @@ def main():
         bounds = sharded.uniform_bounds(n, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
-        sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend)
+        sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend,
+                                  **options)
         v, f = rank, 0
-    else:                                                          # the bench's distributed generator on a pv x pf grid
+    elif mode == "directed":                                       # asymmetric pattern: column sums != row sums, send rows need not be boundary rows
+        n = 640
+        rng = np.random.default_rng(11)
+        coo = np.stack([rng.integers(n, size=5000), (rng.random(5000) ** 3 * n).astype(np.int64)], 1)
+        vals = (rng.random(5000).astype(np.float32) + 0.5)
+        bounds = sharded.uniform_bounds(n, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
+        sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend,
+                                  **options)
+        v, f = rank, 0
+    else:
         if mode.startswith("grid"):
             pv, pf = (int(x) for x in mode[4:].split("x"))
-        sg, _, (v, f, pv, pf) = sharded.build_rmat_shard(500, 6000, seed=1, device=dev, backend=backend, grid=(pv, pf))
+        if mode == "blocks":                                       # the bench's strong-scaling generator (one global graph)
+            sg, _, (v, f, pv, pf) = sharded.build_rmat_blocks(1500, 16000, seed=1, device=dev, backend=backend, **options)
+        else:                                                      # the weak-scaling generator on a pv x pf grid
+            sg, _, (v, f, pv, pf) = sharded.build_rmat_shard(500, 6000, seed=1, device=dev, backend=backend, grid=(pv, pf), **options)
         n, lo, hi = sg.n_global, sg.lo, sg.hi
     cs = C // pf                                                   # this rank's feature slice
     H0_full = np.random.default_rng(1).uniform(-1, 1, size=(n, C)).astype(np.float32)
@@ -92,25 +126,30 @@ def main():
     out = sg.propagate(state, a, K).clone()
     again = sg.propagate(state, a, K).clone()
     assert torch.equal(out, again), "propagate is not repeatable"
-    assert sg.n_buf == sg.n_low + sg.n_local + sg.n_high and sum(sg.recv_counts) == sg.n_low + sg.n_high
-    assert sg.recv_counts[sg.rank] == 0 and sg.send_counts[sg.rank] == 0 and sg.world == pv
-    if pv == 1:
-        assert sg.n_low + sg.n_high == 0                           # feature slices alone: no halo, no exchange
-        assert sg.row_order is not None                            # ... and the shard is stored degree-relabelled
+    zero = sg.propagate(state, a, 0)
+    assert torch.equal(zero, H0), "K = 0 must return H0 in the caller's order"
+    one = sg.propagate(sg.make_state(H0, chunks=1) if sg.world > 1 else state, a, K)
+    np.testing.assert_allclose(one.cpu().numpy(), out.cpu().numpy(), rtol=1e-6, atol=1e-7)   # chunking does not change a column's sums
 
-    # every rank's shard, mapped back to global ids (undoing the monotonic column remap)
-    rowptr, colidx, nvals = (t.cpu().numpy() for t in sg.backend.csr_arrays(sg.graph))
-    halo = sg.halo_ids.cpu().numpy()
-    pos = colidx.astype(np.int64)
-    gcol = np.where(pos < sg.n_low, halo[np.minimum(pos, max(len(halo) - 1, 0))] if len(halo) else 0,
-                    np.where(pos < sg.n_low + sg.n_local, pos - sg.n_low + lo,
-                             halo[np.clip(pos - sg.n_local, 0, max(len(halo) - 1, 0))] if len(halo) else 0))
-    grow = np.repeat(np.arange(sg.n_local), np.diff(rowptr)) + lo
-    if sg.row_order is not None:                                   # relabelled single-block shard: back to the caller's ids
-        order = sg.row_order.cpu().numpy()
-        grow, gcol = order[grow], order[gcol]
-        csr = np.lexsort((gcol, grow))
-        grow, gcol, nvals = grow[csr], gcol[csr], nvals[csr]
+    # plan invariants
+    assert sg.world == pv and sg.recv_counts[sg.rank] == 0 and sg.send_counts[sg.rank] == 0
+    assert sg.n_buf == sg.n_local + sum(sg.recv_counts)
+    assert sg.stats["pull_rows"] + sg.stats["push_rows"] == sum(sg.recv_counts) and sg.stats["send_rows"] == sum(sg.send_counts)
+    assert sg.stats["pull_rows"] + sg.stats["push_rows"] <= sg.stats["pull_only_rows"]       # a cover never moves more rows than the halo
+    if options["cover"] == "pull":
+        assert sg.stats["push_rows"] == 0 and sg.stats["pull_rows"] == sg.stats["pull_only_rows"]
+    if pv == 1:
+        assert sum(sg.recv_counts) == 0                            # feature slices alone: no halo, no exchange
+        if mode != "blocks":
+            assert sg.row_order is not None                        # ... and the weak generator stores the shard degree-relabelled
+    plans = [None] * world
+    dist.all_gather_object(plans, (v, f, sg.send_counts, sg.recv_counts))
+    for pv_, pf_, sends, recvs in plans:                           # what I send to q is what q expects from me
+        if pf_ == f:
+            assert sends[v] == sg.recv_counts[pv_] and recvs[v] == sg.send_counts[pv_]
+
+    # every rank's entries (global ids, normalised values) against the single-process normalisation
+    grow, gcol, nvals, pushed = (None if t is None else t.cpu().numpy() for t in sg.entries)
     parts = [None] * world
     dist.all_gather_object(parts, (v, f, lo, hi, grow, gcol, nvals, out.cpu().numpy()))
     first = sorted([p for p in parts if p[1] == 0], key=lambda p: p[0])     # one feature slice holds the whole graph once
@@ -123,27 +162,32 @@ def main():
     for p in parts:                                                # every feature slice of a vertex block holds the same shard
         twin = [q for q in first if q[0] == p[0]][0]
         assert np.array_equal(p[4], twin[4]) and np.array_equal(p[5], twin[5]) and np.array_equal(p[6], twin[6])
-    if mode == "slices":
+    if mode in ("slices", "directed"):
         raw_coo, raw_vals = coo, vals
-    else:                                                          # generator: unit weights on the union of the shards' patterns
+    else:                                                          # generators: unit weights on the union of the shards' patterns
         raw_coo, raw_vals = np.stack([g_rows, g_cols], 1), np.ones(len(g_rows), dtype=np.float32)
         key = g_rows * n + g_cols
         assert len(np.unique(key)) == len(key) and set(key.tolist()) == set((g_cols * n + g_rows).tolist())   # symmetric, no dups
         assert (g_rows != g_cols).all()
+        if mode == "blocks":
+            assert len(key) == 16000                               # exactly the requested number of stored entries
     ai, av = orc.get_adjacency(raw_coo, raw_vals, (n, n))
     _, _, want_vals = orc.coo_to_csr_coalesced(ai, av, (n, n))
     np.testing.assert_allclose(g_vals, want_vals, rtol=2e-6)       # normalised shard values == single-process normalisation
     want = orc.appnp_propagate(raw_coo, raw_vals, (n, n), H0_full, a=a, iterations=K)
     np.testing.assert_allclose(got_all, want, rtol=1e-4, atol=1e-5)
     assert (got_all.argmax(1) == want.argmax(1)).all()
-    if on_gpu:                                                     # against ONE GPU holding the whole graph: same summation order
+    if on_gpu:                                                     # against ONE GPU holding the whole graph
         import gnntf
         whole = gnntf.normalize(gnntf.DeviceGraph(gnntf.SparseCOO(raw_coo, raw_vals, (n, n)), device=dev), "symmetric")
         single = gnntf.appnp_propagate(whole, torch.from_numpy(H0_full).to(dev), a, K).cpu().numpy()
-        tol = (1e-5, 1e-6) if sg.row_order is not None else (1e-6, 1e-7)    # relabelling changes the summation order
+        # pull-only plans keep the one-GPU summation order; pushed partial sums / relabelling change it
+        exact_order = options["cover"] == "pull" and sg.row_order is None
+        tol = (1e-6, 1e-7) if exact_order else (1e-5, 1e-6)
         np.testing.assert_allclose(got_all, single, rtol=tol[0], atol=tol[1])
     if rank == 0:
-        print("OK", mode, "world", world, "grid", f"{pv}x{pf}", "nnz", sg.nnz_global, "halo", sg.n_low + sg.n_high, "kernel", sg.graph.last_kernel())
+        print("OK", mode, "world", world, "grid", f"{pv}x{pf}", "nnz", sg.nnz_global, "stats", sg.halo_stats() if False else sg.stats,
+              "kernel", sg.graph.last_kernel())
     dist.barrier()
     dist.destroy_process_group()
 

@@ -581,26 +581,3 @@ def test_full_size_properties(gnntf):
     l = (gnntf.spmm(sym, x).double() * y.double()).sum()
     r = (x.double() * _launch(sym, y, None, 1.0, 0.0, 0, transposed=True).double()).sum()
     assert abs(float(l - r)) <= 1e-6 * abs(float(l))
-
-
-def test_config4_full_size_eigenvector(gnntf):
-    """BASELINE config 4 at full size (RMAT 10M vertices / 100M stored entries, C=256, K=10): sqrt(degree)
-    is an eigenvector of D^-1/2 A D^-1/2 with eigenvalue 1 (and 0 on isolated vertices), so propagating
-    H0[i,:] = sqrt(deg_i) must return H0 for every K -- a closed-form answer that needs no CPU run."""
-    import argparse
-    import bench
-    g, adj, _ = bench.build_single(argparse.Namespace(nodes=10_000_000, entries=100_000_000), torch.device("cuda:0"))
-    assert g.n_rows == 10_000_000 and g.nnz == 100_000_000
-    rowptr, colidx, raw = g.csr_arrays()
-    assert bool((raw == 1).all())
-    deg = (rowptr[1:] - rowptr[:-1]).float()
-    H0 = deg.sqrt().unsqueeze(1).expand(-1, 256).contiguous()
-    out = gnntf.appnp_propagate(adj, H0, a=0.1, iterations=10)
-    err = (out - H0).abs().max().item()
-    assert err <= 2e-4 * float(H0.max()), err
-    assert torch.equal(out[deg == 0], H0[deg == 0])                       # isolated rows: a*0 + ... = 0 exactly
-    # symmetry of the stored pattern: x^T (A y) == (A x)^T y on random vectors
-    x = torch.rand(g.n_rows, 8, device="cuda"); y = torch.rand(g.n_rows, 8, device="cuda")
-    l = (x.double() * gnntf.spmm(adj, y).double()).sum(); r = (gnntf.spmm(adj, x).double() * y.double()).sum()
-    assert abs(float(l - r)) <= 1e-6 * abs(float(l))
-    assert g.last_kernel() == "spmm_group4"

@@ -32,3 +32,25 @@ def test_c_port_matches_numpy_oracle(cport, K, C):
     want = orc.appnp_propagate(coo, vals, shape, H0, a=0.1, iterations=K)
     np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-6)
     assert cport.oracle_num_threads() >= 1
+
+
+def test_c_port_sample_iteration_parallel_normalisation(cport):
+    """bench.py's cpu_baseline entry: one iteration on a row prefix, normalisation spread over the threads (atomic column
+    sums: same values up to float summation order) or skipped (values taken as A_hat's)."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(800, 7000, seed=9)
+    vals = (vals * np.random.default_rng(0).uniform(0.5, 2.0, size=len(vals))).astype(np.float32)
+    rowptr, colidx, cvals = orc.coo_to_csr_coalesced(coo, vals, shape)
+    C, rows = 12, 300
+    H = np.random.default_rng(1).uniform(-1, 1, size=(800, C)).astype(np.float32)
+    H0 = np.random.default_rng(2).uniform(-1, 1, size=(800, C)).astype(np.float32)
+    fn = cport.oracle_sample_iteration_par
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
+    out = np.empty((rows, C), dtype=np.float32)
+    assert fn(800, rows, rowptr.ctypes.data, colidx.ctypes.data, cvals.ctypes.data, H.ctypes.data, H0.ctypes.data, 0.1, C, out.ctypes.data, 1) == 0
+    ai, av = orc.get_adjacency(coo, vals, shape)
+    want = orc.ppr_iteration(ai, av, shape, H, H0, 0.1)
+    np.testing.assert_allclose(out, want[:rows], rtol=1e-5, atol=1e-6)
+    assert fn(800, rows, rowptr.ctypes.data, colidx.ctypes.data, cvals.ctypes.data, H.ctypes.data, H0.ctypes.data, 0.1, C, out.ctypes.data, 0) == 0
+    want_raw = orc.ppr_iteration(coo, vals, shape, H, H0, 0.1)
+    np.testing.assert_allclose(out, want_raw[:rows], rtol=1e-5, atol=1e-6)

@@ -1,6 +1,6 @@
-"""World-size-2 (and 3) gloo runs of the vertex-partitioned propagation on CPU ranks: partition,
-halo plan, pairwise exchange and ping-pong logic of gnntf.sharded, checked against the
-single-process oracle."""
+"""World-size-2/3/4 gloo runs of the vertex-partitioned propagation on CPU ranks: partition, pull/push halo
+plan (vertex cover), pairwise exchange, interior/boundary split, column-chunk pipelining and the ping-pong
+logic of gnntf.sharded, checked against the single-process oracle."""
 import os
 import socket
 import subprocess
@@ -17,18 +17,32 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, mode, device="cpu"):
+def launch(world, mode, device="cpu", options="cover,split,2"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), mode, device]
+           "--master-port", str(free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), mode, device, options]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "OK " + mode in res.stdout
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_matches_single_process_oracle(world):
-    launch(world, "slices")
+@pytest.mark.parametrize("world,options", [(2, "cover,split,2"), (3, "cover,split,2"), (2, "pull,whole,1"), (3, "pull,split,3")])
+def test_sharded_matches_single_process_oracle(world, options):
+    """Fixed graph with duplicates, uneven blocks: cover and pull-only plans, split and whole rows, 1-3 chunks."""
+    launch(world, "slices", options=options)
+
+
+@pytest.mark.parametrize("world,options", [(2, "cover,split,2"), (3, "cover,whole,2")])
+def test_sharded_directed_pattern(world, options):
+    """Asymmetric pattern: column sums differ from row sums, rows to send need not be boundary rows, and the
+    greedy cover can lose to the plain halo for a peer (which then keeps the plain halo)."""
+    launch(world, "directed", options=options)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strong_scaling_generator(world):
+    """bench.py's N > 1 workload: ONE global graph cut into `world` vertex blocks (rank 0 generates, broadcast)."""
+    launch(world, "blocks")
 
 
 def test_distributed_generator_world2():
@@ -41,24 +55,48 @@ def test_feature_sliced_grid(world, grid):
     launch(world, grid)
 
 
-def test_choose_grid():
-    """Cost model of DESIGN.md section 5: wide features -> slices (no exchange); medium -> vertex blocks."""
-    from gnntf.sharded import choose_grid, grid_cost_ms
-    for world in (2, 4, 8):
-        assert choose_grid(world, 256, 10_000_000 * world, 100_000_000 * world) == (1, world)
-    assert choose_grid(8, 128, 80_000_000, 800_000_000) == (1, 8)
-    assert choose_grid(8, 64, 80_000_000, 800_000_000) == (8, 1)
-    assert choose_grid(8, 7, 80_000_000, 800_000_000) == (8, 1)          # 7 columns cannot be sliced
-    assert choose_grid(1, 256) == (1, 1)
-    assert choose_grid(8, 256, 80_000_000, 800_000_000, link_GBs=1e6) == (8, 1)   # free links -> keep rows wide
-    assert abs(grid_cost_ms(1, 8, 256, 80_000_000, 800_000_000) - 20.0) < 1.0      # measured: 22.3 ms
-    assert abs(grid_cost_ms(1, 1, 256, 10_000_000, 100_000_000) - 16.2) < 0.5      # measured: 16.2 ms
+def test_choose_grid_and_columns():
+    """Planning helpers: the grid cost model takes a MEASURED link rate (no built-in default), and the column
+    chunks are whole 128-byte lines wherever the width allows."""
+    from gnntf.sharded import choose_grid, grid_cost_ms, split_columns
+    big = dict(nodes_total=80_000_000, entries_total=1_000_000_000)
+    assert choose_grid(8, 128, link_GBs=1e6, **big) == (8, 1)                  # free links -> keep rows wide
+    assert choose_grid(8, 128, link_GBs=1.0, **big) == (1, 8)                  # very slow links -> replicate the graph instead
+    assert choose_grid(8, 7, link_GBs=1.0, **big) == (8, 1)                    # 7 columns cannot be sliced
+    assert choose_grid(1, 256, link_GBs=50.0, **big) == (1, 1)
+    assert abs(grid_cost_ms(1, 1, 256, 10_000_000, 100_000_000, link_GBs=50.0) - 16.2) < 0.5      # measured: 16.2 ms
+    with pytest.raises(TypeError):
+        choose_grid(8, 128, 80_000_000, 1_000_000_000)                          # the link rate must be given
+    assert split_columns(128, 2) == [(0, 64), (64, 128)]
+    assert split_columns(128, 3) == [(0, 32), (32, 64), (64, 128)]
+    assert split_columns(12, 2) == [(0, 4), (4, 12)] or split_columns(12, 2) == [(0, 8), (8, 12)]
+    assert split_columns(7, 2) == [(0, 3), (3, 7)]
+    assert split_columns(5, 9)[-1][1] == 5 and len(split_columns(5, 9)) == 5
+
+
+def test_cover_push_mask_properties():
+    """The pull/push decision: every pushed entry's (peer, row) is pushed as a whole, a star's leaves are covered by
+    its hub from both sides, and a peer whose cover is not smaller keeps the plain halo."""
+    import torch
+    from gnntf.sharded import cover_push_mask
+    bnd = torch.tensor([10, 20])
+    # rank 0 owns 0..9; row 0 is a hub with 6 columns on rank 1 (ids 10..15); rows 1..3 all reference column 19 (a remote hub)
+    row = torch.tensor([0, 0, 0, 0, 0, 0, 1, 2, 3, 4])
+    col = torch.tensor([10, 11, 12, 13, 14, 15, 19, 19, 19, 5])
+    owner = torch.bucketize(col, bnd, right=True)
+    push = cover_push_mask(row, col, owner, 0, 10, bnd)
+    assert push.tolist() == [True] * 6 + [False] * 4          # the hub row is pushed (1 row instead of 6), column 19 pulled, local entry untouched
+    # two rows sharing the same two remote columns: the plain halo (2 rows) is not beaten -> all pull
+    row2 = torch.tensor([0, 0, 1, 1]); col2 = torch.tensor([10, 11, 10, 11])
+    assert not cover_push_mask(row2, col2, torch.bucketize(col2, bnd, right=True), 0, 10, bnd).any()
+    assert not cover_push_mask(row, col, torch.zeros_like(owner), 0, 10, torch.tensor([20])).any()   # one block: nothing to cover
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["slices", "rmat", "grid1x2"])
-def test_sharded_native_backend_two_ranks_one_gpu(mode):
-    """The libgnx.so backend on real shards (rectangular local CSR, halo columns, output view inside
-    the ping-pong buffer): two ranks share cuda:0 and exchange halos over gloo (staged through the host;
-    RCCL needs one GPU per rank, which the single-GPU box cannot give)."""
-    launch(2, mode, "cuda")
+@pytest.mark.parametrize("mode,options", [("slices", "cover,split,2"), ("slices", "pull,whole,1"), ("blocks", "cover,split,2"),
+                                          ("rmat", "cover,whole,2"), ("grid1x2", "cover,split,2")])
+def test_sharded_native_backend_two_ranks_one_gpu(mode, options):
+    """The libgnx.so backend on real shards (rectangular CSR over [regions | local | regions], interior / boundary
+    handles with row maps, the send CSR, exchange on its own stream): two ranks share cuda:0 and exchange over gloo
+    (staged through the host; RCCL needs one GPU per rank, which the single-GPU box cannot give)."""
+    launch(2, mode, "cuda", options)

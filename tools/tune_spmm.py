@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of SpMM kernel variants in ONE process (cdna guide rule 24).
+Needs a TUNING build of the library (the product build has no variant switches):
+    make -C gnn-tf_amd/csrc clean && make -C gnn-tf_amd/csrc TUNING=1
     python tools/tune_spmm.py --feats 256 --variants 0,1,2,3,6,7,16,32,48,64"""
 import argparse
 import ctypes
@@ -29,6 +31,8 @@ def main():
     gnntf.set_default_device(dev)
     g, adj, _ = bench.build_single(a, dev)
     lib = nat.lib()
+    if not hasattr(lib, "gnx_debug_set_tune"):
+        raise SystemExit("tune_spmm.py needs a tuning build: make -C gnn-tf_amd/csrc clean && make -C gnn-tf_amd/csrc TUNING=1")
     lib.gnx_debug_set_tune.argtypes = [ctypes.c_int]
     n, C = g.n_rows, a.feats
     H = torch.rand(n, C, device=dev) * 2 - 1
