@@ -116,14 +116,16 @@ def timed_steps(step, steps, warmup, barrier):
 def stream_copy_GBs(device, nbytes=4 << 30, reps=5):
     """Device stream-copy rate (read + write bytes per second) measured in this run: the achievable HBM peak."""
     import torch
+    from gnntf import _native as nat
     src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
     dst = torch.empty_like(src)
-    dst.copy_(src)
+    copy = lambda: nat.check(nat.lib().gnx_stream_copy(nat.ptr(src), nat.ptr(dst), src.numel(), nat.current_stream()))
+    copy()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(reps):
-        dst.copy_(src)
+        copy()
     e.record()
     torch.cuda.synchronize()
     return 2.0 * nbytes * reps / (s.elapsed_time(e) * 1e-3) / 1e9

@@ -169,6 +169,10 @@ class Comm:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
 
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)
+
     def alltoallv(self, chunks):
         """chunks[q]: a 1-D tensor for group rank q (any length).  Returns what every rank sent to this one."""
         if self.size == 1:
@@ -647,8 +651,7 @@ class ShardedGraph:
     def _sync(self):
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        if self.world > 1:
-            dist.barrier(group=self.group)
+        self.comm.barrier()
 
     def halo_stats(self):
         """Max over ranks of the plan sizes (rows): what crosses the links per iteration and how the rows split."""

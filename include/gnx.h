@@ -169,6 +169,10 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,
                     float *d_out, int64_t ldo, void *stream);
 
+/* Measurement aid: a float4 streaming copy d_dst[0..n) = d_src[0..n) (n a multiple of 4, 16-byte aligned pointers).
+ * bench.py times it next to the propagation as the measured-peak HBM rate (read + write bytes per second). */
+int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *stream);
+
 /* Name of the SpMM kernel the last gnx_spmm/_t call on this handle dispatched (static
  * string; for profiles and tests). */
 const char *gnx_graph_last_kernel(gnx_graph_t g);

@@ -4,8 +4,8 @@
     python profiles/summarize.py <tag> <stats_dir> [<fetch_dir> <write_dir>] [--workload NAME]
 
 Writes profiles/<tag>_kernel_stats.csv (top kernels of `rocprofv3 --kernel-trace --stats`) and, when
-the two PMC passes are given, profiles/<tag>_pmc.csv plus profiles/pmc_traffic.json (HBM-side
-bytes per propagation launch).  PMC correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE
+the two PMC passes are given, profiles/<tag>_pmc.csv plus this workload's entry of profiles/pmc_traffic.json
+(bytes leaving the L2s per propagation launch; Infinity-Cache hits are counted in them).  PMC correction (MI355X_MICROARCH.md, "HBM"): FETCH_SIZE and WRITE_SIZE
 are in KiB; on gfx950 FETCH_SIZE counts 128-B requests of wide (16 B/lane) coalesced reads as 64 B, so
 the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 """
@@ -63,11 +63,11 @@ def main():
             rd, wr = 2 * fetch * 1024, write * 1024
             total += rd + wr
             f.write(f"\"{k}\",{len(c['FETCH_SIZE'])},{sum(c['ms'])/len(c['ms']):.4f},{fetch:.1f},{write:.1f},{rd:.4e},{wr:.4e},{rd+wr:.4e}\n")
-    json.dump({"workload": workload, "hbm_bytes_per_launch": total,
-               "note": "sum over the kernels of one propagation iteration (spmm + long-row partial + reduce); "
-                       "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes; separate --pmc passes"},
-              open(os.path.join(HERE, "pmc_traffic.json"), "w"), indent=1)
-    print("hbm bytes per launch: %.4e" % total)
+    path = os.path.join(HERE, "pmc_traffic.json")
+    rec = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
+    rec.setdefault("workloads", {})[workload] = {"fabric_bytes_per_launch": total, "source": f"{tag}_pmc.csv"}
+    json.dump(rec, open(path, "w"), indent=1)
+    print("fabric bytes per launch: %.4e" % total)
 
 
 if __name__ == "__main__":

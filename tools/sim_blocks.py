@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""ONE rank's share of the P-GPU strong-scaling run, rehearsed on one GPU: builds vertex block ``--rank`` of the
+config-5 graph exactly as bench.py --gpus P would (same generator, same pull/push cover plan, same kernels) with a
+loop-back communicator, and reports the plan sizes and the measured per-iteration kernel time of that block.
+
+The loop-back mirrors what the peers would ask of this rank: the bench graph's pattern and normalised values are
+symmetric, so the plan of the pair (q <- r) is the plan of (r <- q) with rows and columns swapped -- computed here from
+this rank's own cross entries.  The exchange itself copies this rank's outgoing rows into its own halo regions (same
+sizes by that symmetry), so only link time is missing; predicted iteration time = max(kernels, halo bytes / link rate).
+
+    python tools/sim_blocks.py --world 8 --rank 0 > gpurun_out/sim_blocks_p8.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd")]
+import torch
+
+import bench
+import gnntf
+from gnntf import sharded
+
+
+class LoopbackComm(sharded.Comm):
+    def __init__(self, world, rank, degrees):
+        self.group, self.solo, self.rank, self.size = None, False, rank, world
+        self.degrees, self.sg, self.calls = degrees, None, 0
+
+    def _staged(self, t):
+        return False
+
+    def barrier(self):
+        pass
+
+    def broadcast(self, t, src=0):
+        return t
+
+    def all_reduce(self, t, op=None):
+        if t.numel() == self.degrees.numel() and t.dtype == torch.float32:
+            t.copy_(self.degrees)                       # the global column sums (unit weights: the degrees)
+        return t
+
+    def exchange(self, send_chunks, recv_chunks):
+        for s, r in zip(send_chunks, recv_chunks):      # about the same sizes by symmetry: stand in for the peer's rows
+            if s is not None and r is not None:
+                m = min(s.shape[0], r.shape[0])
+                r[:m].copy_(s[:m])
+
+    def all_gather_vec(self, t):                        # push_counts table: table[q][me] = rows q asks me to sum for it
+        table = [torch.zeros_like(t) for _ in range(self.size)]
+        for q in range(self.size):
+            if q != self.rank:
+                table[q][self.rank] = self.n_pushed_for[q]
+        table[self.rank] = t
+        return table
+
+    def alltoallv(self, chunks):
+        """Called three times by ShardedGraph._build_block: pulled ids, push edges (slot, col), push values."""
+        sg, P, me = self.sg, self.size, self.rank
+        if self.calls == 0:
+            self._mirror()
+        kind = self.calls % 3
+        self.calls += 1
+        return [self.mirrored[q][kind] if q != me else chunks[me] for q in range(P)]
+
+    def _mirror(self):
+        sg, P, me = self.sg, self.size, self.rank
+        rows_g, cols_g, nvals, _ = sg.entries
+        dev = rows_g.device
+        bnd = torch.tensor(sg.bounds[1:], dtype=torch.int64, device=dev)
+        owner = torch.bucketize(cols_g, bnd, right=True)
+        self.mirrored, self.n_pushed_for = {}, {}
+        for q in range(P):
+            if q == me:
+                continue
+            sel = owner == q
+            lo_q, n_q = sg.bounds[q], sg.bounds[q + 1] - sg.bounds[q]
+            t_row = cols_g[sel] - lo_q                                  # q's local row (my column j)
+            t_col = rows_g[sel]                                         # global id of my row i: q's remote column
+            t_own = torch.full_like(t_col, me)
+            push = sharded.cover_push_mask(t_row, t_col, t_own, q, n_q, bnd) if sg.cover == "cover" else torch.zeros_like(sel[sel])
+            asked = torch.unique(t_col[~push])                          # q pulls these rows of mine
+            keys = torch.unique(t_row[push])                            # q's pushed rows for peer me, ascending = slot order
+            slot = torch.searchsorted(keys, t_row[push]) if keys.numel() else torch.zeros(0, dtype=torch.int64, device=dev)
+            edges = torch.stack([slot, t_col[push]], 1).reshape(-1)
+            self.mirrored[q] = (asked, edges, nvals[sel][push])
+            self.n_pushed_for[q] = int(keys.numel())
+        return
+
+
+class SimGraph(sharded.ShardedGraph):
+    def _build_block(self, row, col, nvals, split_rows):
+        self.comm.sg = self
+        return super()._build_block(row, col, nvals, split_rows)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--nodes", type=int, default=80_000_000)
+    ap.add_argument("--entries", type=int, default=1_000_000_000)
+    ap.add_argument("--feats", type=int, default=128)
+    ap.add_argument("--cover", default="cover")
+    ap.add_argument("--chunks", type=int, default=2)
+    ap.add_argument("--whole-rows", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    gnntf.set_default_device(dev)
+    P, r, N = a.world, a.rank, a.nodes
+    t0 = time.time()
+    u, w = sharded.rmat_relabelled_pairs(N, a.entries // 2, seed=1, device=dev)
+    degrees = (torch.bincount(u, minlength=N) + torch.bincount(w, minlength=N)).float()
+    bounds = sharded.uniform_bounds(N, P)
+    lo, hi = bounds[r], bounds[r + 1]
+    mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
+    idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
+    del u, w, mu, mw
+    vals = torch.ones(idx.shape[0], dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    t0 = time.time()
+    comm = LoopbackComm(P, r, degrees)
+    sg = SimGraph(idx, vals, bounds, comm=comm, cover=a.cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True)
+    sg.entries = None
+    del idx, vals, comm.mirrored
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    t_plan = time.time() - t0
+    C = a.feats
+    H0 = torch.rand(sg.n_local, C, device=dev) * 2 - 1
+    state = sg.make_state(H0)
+    t_c = sg.time_compute(state, 0.1)
+    t_x = sg.time_exchange(state)                                       # loop-back copies: local HBM traffic only
+    sg.propagate(state, 0.1, 10)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(3):
+        sg.propagate(state, 0.1, 10)
+    torch.cuda.synchronize()
+    t_step = (time.time() - t0) / 3
+    st = sg.stats
+    halo_rows = st["pull_rows"] + st["push_rows"]
+    out = {"world": P, "rank": r, "graph": {"nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
+           "split_rows": bool(sg.split_rows)}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
+           "local_entries": sg.nnz_local, "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
+           "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
+           "loopback_copy_ms_per_iteration": t_x * 1e3, "step_ms_K10_loopback": t_step * 1e3,
+           "predicted_iteration_ms": {f"{bw}_GBs_per_link": max(t_c * 1e3, halo_rows * C * 4 / ((P - 1) * bw * 1e9) * 1e3) for bw in (30, 45, 60, 75)},
+           "kernel": sg.graph.last_kernel()}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
