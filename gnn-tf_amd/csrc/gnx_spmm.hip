@@ -381,11 +381,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
     }
 }
 
-// float4 grid-stride copy: the achievable-HBM-bandwidth yardstick bench.py measures beside the SpMM
+// float4 grid-stride copy, four independent 16-byte loads in flight per lane: the achievable-HBM-bandwidth
+// yardstick bench.py measures beside the SpMM
 __global__ __launch_bounds__(256) void k_stream_copy(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -623,7 +628,7 @@ int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *st
     GNX_CHECK_ARG(n_floats >= 0 && n_floats % 4 == 0, "gnx_stream_copy: the length must be a multiple of 4 floats");
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_dst && aligned(d_src, 16) && aligned(d_dst, 16), "gnx_stream_copy: NULL or unaligned pointer");
-    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst, n_floats / 4);
+    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst, n_floats / 4);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
