@@ -250,7 +250,35 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     ms = median_ms(train_step, reps=3, warm=1)
     out["training_step_C64"] = {"ms": ms, "what": f"forward + backward of {K} PPR iterations with per-iteration edge dropout 0.5 + "
                                 f"renormalisation, config-4 graph, C=64", "edges_per_s": 2 * nnz * K / ms * 1e3}
-    del H0, gout, g, adj
+    del H0, gout
+    torch.cuda.empty_cache()
+    # the matrix-core ends of the path at the config-4 size
+    mf = {}
+    C = 64
+    H, H0 = torch.rand(n, C, device=device) * 2 - 1, torch.rand(n, C, device=device) * 2 - 1
+    M = 0.6 * torch.eye(C, device=device) + 0.4 * torch.randn(C, C, device=device) / 8
+    with torch.no_grad():
+        t_fused = median_ms(lambda: gnntf.gcnii_step(adj, H, H0, a, M, relu=True), reps=5, warm=2)
+        kernel = g.last_kernel()
+        t_two = median_ms(lambda: gnntf.dense(gnntf.ppr_step(adj, H, H0, a), M, None, relu=True), reps=5, warm=2)
+    mf["gcnii_layer_C64"] = {"fused_ms": t_fused, "spmm_then_dense_ms": t_two, "kernel": kernel,
+                             "what": "relu(((1-a) A.H + a H0) . M) on the config-4 graph: one launch (mixed rows stay in LDS, MFMA epilogue) vs "
+                                     "fused SpMM+mix followed by gnx_dense"}
+    del H, H0
+    X = torch.randn(n, 256, device=device)
+    W, b = torch.randn(256, 64, device=device) / 16, torch.randn(1, 64, device=device)
+    with torch.no_grad():
+        t_dense = median_ms(lambda: gnntf.dense(X, W, b, relu=True), reps=5, warm=2)
+    mf["dense_10M_x_256_to_64_relu"] = {"ms": t_dense, "TFLOPs": 2.0 * n * 256 * 64 / t_dense / 1e9, "GBs": (n * 256 * 4 + n * 64 * 4) / t_dense / 1e6,
+                                        "mfma_peak_TFLOPs": 157.3, "what": "gnx_dense, float32 v_mfma_f32_16x16x4_f32; X read once from HBM"}
+    del X
+    logits = torch.randn(n, 40, device=device)
+    nodes = torch.randperm(n, device=device)[:1_000_000]
+    labels = torch.randint(0, 40, (1_000_000,), device=device)
+    t_head = median_ms(lambda: gnntf.node_ce(logits, nodes, labels), reps=5, warm=2)
+    mf["node_ce_1M_nodes_C40"] = {"ms": t_head, "what": "gather + log-softmax + cross entropy + mean, two launches"}
+    out["matrix_core_kernels"] = mf
+    del logits, nodes, labels, g, adj
     torch.cuda.empty_cache()
     # config 3: arxiv-shaped 2-layer GCN forward (N = 169,343; 1,166,243 undirected pairs -> 2,332,486 stored entries; 128 -> 64 -> 40)
     g3, adj3, _ = build_single(argparse.Namespace(nodes=169_343, entries=2_332_486), device)

@@ -1,0 +1,300 @@
+// The dense ends of the path on gfx950 matrix cores: the pre-MLP transform and the task head.
+//
+//   gnx_dense      out = act(X . W + b)                      reference gnntf/core/nn/layers.py:135-136 (Dense),
+//                                                            gnntf/core/gnn/architectures/gcn.py:89 (the transform of GCNLayer)
+//   gnx_node_ce    mean_i CE(log_softmax(logits[nodes_i]))   reference gnntf/core/gnn/graph_predictor.py:19-25
+//   gnx_node_argmax  argmax(logits[nodes_i])                 reference gnntf/core/gnn/graph_predictor.py:16-17, 27-31
+//
+// gnx_dense is a tall-and-skinny GEMM (N rows in the millions, F and O in the tens to hundreds): float32 in, float32
+// accumulate on v_mfma_f32_16x16x4_f32 (bit-for-bit a k-ordered fmaf chain, no reduced precision).  A 256-thread block owns
+// 64 rows; each of its 4 waves keeps a 16-row x O accumulator strip in registers.  X is read ONCE, straight from HBM into
+// the A operand (16 bytes per lane; the k index inside a 16-wide step is permuted so that a lane's four consecutive floats
+// feed four MFMAs), W streams through LDS in K chunks shared by the block (row stride = 4 mod 32 banks: the four k-groups
+// of a wave read disjoint banks).  Arithmetic intensity is O/2 flop per byte of X: HBM-bound up to O = 32, MFMA-bound beyond.
+#include "gnx_internal.h"
+
+using namespace gnx;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DenseArgs {
+    const float *X; int64_t ldx; int64_t n; int F;
+    const float *W; int64_t ldw; int O;
+    const float *bias;            // [O] or null
+    int act;
+    float *out; int64_t ldo;
+    const int32_t *out_rows;      // optional: result row r goes to out[out_rows[r]]
+    const int32_t *in_rows;       // optional: input row r is X[in_rows[r]]
+};
+
+template <int NT> struct DenseCfg {
+    static constexpr int OP = NT * 16;                 // padded output width
+    static constexpr int KC = NT <= 4 ? 64 : 32;       // W rows per LDS chunk
+    static constexpr int STRIDE = OP + 4;              // OP is a multiple of 16; +4 makes row stride = 4 (mod 8): see header
+};
+
+template <int NT, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
+    using Cfg = DenseCfg<NT>;
+    __shared__ float Ws[Cfg::KC * Cfg::STRIDE];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    int64_t arow = row0 + c < p.n ? row0 + c : p.n - 1;                  // rows past the end read a valid row and are not stored
+    if (p.in_rows) arow = p.in_rows[arow];
+    const float *__restrict__ xrow = p.X + arow * p.ldx;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < p.F; k0 += Cfg::KC) {
+        __syncthreads();                                                   // the previous chunk has been consumed
+        for (int idx = threadIdx.x; idx < Cfg::KC * Cfg::OP; idx += 256) {
+            const int r = idx / Cfg::OP, cc = idx % Cfg::OP;
+            const int k = k0 + r;
+            Ws[r * Cfg::STRIDE + cc] = (k < p.F && cc < p.O) ? p.W[(int64_t)k * p.ldw + cc] : 0.f;
+        }
+        float a[Cfg::KC / 16][4];
+#pragma unroll
+        for (int T = 0; T < Cfg::KC / 16; ++T) {                           // every A value of the chunk in flight before the first MFMA
+            const int kb = k0 + 16 * T + 4 * g;
+            if (ALIGNED && kb + 3 < p.F) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + kb);
+                a[T][0] = v[0]; a[T][1] = v[1]; a[T][2] = v[2]; a[T][3] = v[3];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a[T][t] = kb + t < p.F ? xrow[kb + t] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int T = 0; T < Cfg::KC / 16; ++T) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *__restrict__ wrow = Ws + (16 * T + 4 * g + t) * Cfg::STRIDE + c;   // B[k-slot g][col c] = W[k0 + 16T + 4g + t][16 nt + c]
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T][t], wrow[16 * nt], acc[nt], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: lane (c, g), register r -> row 4g + r, column 16 nt + c
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = 16 * nt + c;
+        if (col >= p.O) continue;
+        const float b = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * g + r;
+            if (row >= p.n) continue;
+            float v = acc[nt][r] + b;
+            if (p.act == GNX_ACT_RELU) v = fmaxf(v, 0.f);
+            const int64_t orow = p.out_rows ? (int64_t)p.out_rows[row] : row;
+            p.out[orow * p.ldo + col] = v;
+        }
+    }
+}
+
+template <int NT>
+void launch_dense(const DenseArgs &p, bool aligned, hipStream_t s) {
+    const unsigned grid = (unsigned)((p.n + 63) / 64);
+    if (aligned) hipLaunchKernelGGL((k_dense_mfma<NT, true>), dim3(grid), dim3(256), 0, s, p);
+    else         hipLaunchKernelGGL((k_dense_mfma<NT, false>), dim3(grid), dim3(256), 0, s, p);
+}
+
+// ---- task head -----------------------------------------------------------------------------------------------------------
+// One 16-lane group per listed node: gather the row, max, sum of exponentials, loss_i = logsumexp - x[label]
+// (graph_predictor.py:24-25: CE-from-logits applied to log_softmax(x); softmax(log_softmax(x)) = softmax(x), so this IS the
+// plain cross entropy).  Fixed reduction trees: bitwise reproducible.
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_node_ce_fwd(const float *__restrict__ logits, int64_t ldl, int C, int64_t n_rows,
+                                                      const int64_t *__restrict__ nodes, const int64_t *__restrict__ labels, int64_t m,
+                                                      float *__restrict__ loss, int *__restrict__ bad) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= m) return;
+    const int64_t node = nodes[i], label = labels[i];
+    if (node < 0 || node >= n_rows || label < 0 || label >= C) {
+        if (sub == 0) { atomicExch(bad, 1); loss[i] = 0.f; }
+        return;
+    }
+    const float *__restrict__ x = logits + node * ldl;
+    float mx = -INFINITY;
+    for (int c = sub; c < C; c += 16) mx = fmaxf(mx, x[c]);
+    mx = group16_max(mx);
+    float se = 0.f;
+    for (int c = sub; c < C; c += 16) se += expf(x[c] - mx);
+    se = group16_sum(se);
+    if (sub == 0) loss[i] = (logf(se) + mx) - x[label];
+}
+
+// d logits[node_i, :] += scale * (softmax(x) - onehot(label)); atomics because a node may be listed twice
+__global__ __launch_bounds__(256) void k_node_ce_bwd(const float *__restrict__ logits, int64_t ldl, int C, const int64_t *__restrict__ nodes,
+                                                      const int64_t *__restrict__ labels, int64_t m, const float *__restrict__ gout, float inv_m,
+                                                      float *__restrict__ grad, int64_t ldg) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= m) return;
+    const int64_t node = nodes[i], label = labels[i];
+    const float *__restrict__ x = logits + node * ldl;
+    float mx = -INFINITY;
+    for (int c = sub; c < C; c += 16) mx = fmaxf(mx, x[c]);
+    mx = group16_max(mx);
+    float se = 0.f;
+    for (int c = sub; c < C; c += 16) se += expf(x[c] - mx);
+    se = group16_sum(se);
+    const float scale = gout[0] * inv_m, inv = 1.0f / se;
+    for (int c = sub; c < C; c += 16) {
+        const float pr = expf(x[c] - mx) * inv;
+        atomicAdd(grad + node * ldg + c, scale * (pr - (c == label ? 1.0f : 0.0f)));
+    }
+}
+
+// mean of m values in a fixed order (one block; a fixed LDS tree over 256 strided partial sums)
+__global__ __launch_bounds__(256) void k_mean(const float *__restrict__ v, int64_t m, float *__restrict__ out) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < m; i += 256) acc += v[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)m;
+}
+
+// first index of the row maximum (tf.argmax / np.argmax tie rule)
+__global__ __launch_bounds__(256) void k_node_argmax(const float *__restrict__ logits, int64_t ldl, int C, int64_t n_rows,
+                                                      const int64_t *__restrict__ nodes, int64_t m, int64_t *__restrict__ out, int *__restrict__ bad) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= m) return;
+    const int64_t node = nodes ? nodes[i] : i;
+    if (node < 0 || node >= n_rows) {
+        if (sub == 0) { atomicExch(bad, 1); out[i] = 0; }
+        return;
+    }
+    const float *__restrict__ x = logits + node * ldl;
+    float best = -INFINITY;
+    int arg = C;                                           // rows of NaNs: no element compares greater; report 0 like np.argmax of all-equal
+    for (int c = sub; c < C; c += 16) {
+        const float v = x[c];
+        if (v > best || (v == best && c < arg)) { best = v; arg = c; }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oa = __shfl_xor(arg, off);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (sub == 0) out[i] = arg < C ? arg : 0;
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
+
+}  // namespace
+
+namespace gnx {
+
+// used by gnx_spmm.hip (GCNII's long rows go through the dense kernel with a row scatter)
+int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W, int64_t ldw, int64_t O, const float *bias, int act,
+               const int32_t *in_rows, const int32_t *out_rows, float *out, int64_t ldo, hipStream_t s) {
+    if (n == 0) return GNX_OK;
+    DenseArgs p{X, ldx, n, (int)F, W, ldw, (int)O, bias, act, out, ldo, out_rows, in_rows};
+    const bool al = ldx % 4 == 0 && aligned16(X);
+    for (int64_t o0 = 0; o0 < O; o0 += 256) {                         // column panels of at most 256 outputs
+        DenseArgs q = p;
+        q.W = W + o0; q.bias = bias ? bias + o0 : nullptr; q.out = out + o0;
+        q.O = (int)(O - o0 < 256 ? O - o0 : 256);
+        const int nt = (q.O + 15) / 16;
+        if (nt <= 1) launch_dense<1>(q, al, s);
+        else if (nt <= 2) launch_dense<2>(q, al, s);
+        else if (nt <= 3) launch_dense<3>(q, al, s);
+        else if (nt <= 4) launch_dense<4>(q, al, s);
+        else if (nt <= 6) launch_dense<6>(q, al, s);
+        else if (nt <= 8) launch_dense<8>(q, al, s);
+        else if (nt <= 12) launch_dense<12>(q, al, s);
+        else launch_dense<16>(q, al, s);
+    }
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+}  // namespace gnx
+
+extern "C" {
+
+int gnx_dense(const float *d_X, int64_t ldx, int64_t n, int64_t F, const float *d_W, int64_t ldw, int64_t O, const float *d_bias,
+              int act, float *d_out, int64_t ldo, void *stream) {
+    GNX_CHECK_ARG(n >= 0 && F >= 1 && O >= 1 && F <= (1 << 24) && O <= (1 << 20), "gnx_dense: bad sizes (n=%lld, F=%lld, O=%lld)",
+                  (long long)n, (long long)F, (long long)O);
+    GNX_CHECK_ARG(ldx >= F && ldw >= O && ldo >= O, "gnx_dense: leading dimension smaller than the row");
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_dense: invalid activation %d", act);
+    if (n == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_X && d_W && d_out, "gnx_dense: NULL pointer");
+    GNX_CHECK_ARG((const void *)d_X != (const void *)d_out, "gnx_dense: out must not alias X");
+    return dense_rows(d_X, ldx, n, F, d_W, ldw, O, d_bias, act, nullptr, nullptr, d_out, ldo, (hipStream_t)stream);
+}
+
+int gnx_node_ce(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, const int64_t *d_labels, int64_t m,
+                float *d_loss_per_node, float *d_mean_loss, void *stream) {
+    GNX_CHECK_ARG(m >= 1 && C >= 1 && n_rows >= 1 && ldl >= C, "gnx_node_ce: bad sizes");
+    GNX_CHECK_ARG(d_logits && d_nodes && d_labels && d_loss_per_node && d_mean_loss, "gnx_node_ce: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int *bad = nullptr;
+    GNX_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{bad};
+    GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_node_ce_fwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_logits, ldl, (int)C, n_rows, d_nodes, d_labels, m,
+                       d_loss_per_node, bad);
+    hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, s, d_loss_per_node, m, d_mean_loss);
+    int h_bad = 0;
+    GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    GNX_CHECK_ARG(h_bad == 0, "gnx_node_ce: a node id or a label is out of range");
+    return GNX_OK;
+}
+
+int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t C, const int64_t *d_nodes, const int64_t *d_labels, int64_t m,
+                         const float *d_grad_loss, float *d_grad_logits, int64_t ldg, void *stream) {
+    GNX_CHECK_ARG(m >= 1 && C >= 1 && ldl >= C && ldg >= C, "gnx_node_ce_backward: bad sizes");
+    GNX_CHECK_ARG(d_logits && d_nodes && d_labels && d_grad_loss && d_grad_logits, "gnx_node_ce_backward: NULL pointer");
+    hipLaunchKernelGGL(k_node_ce_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_logits, ldl, (int)C, d_nodes,
+                       d_labels, m, d_grad_loss, 1.0f / (float)m, d_grad_logits, ldg);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_node_argmax(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, int64_t m, int64_t *d_out,
+                    void *stream) {
+    GNX_CHECK_ARG(m >= 0 && C >= 1 && n_rows >= 0 && ldl >= C, "gnx_node_argmax: bad sizes");
+    if (m == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_logits && d_out, "gnx_node_argmax: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int *bad = nullptr;
+    GNX_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{bad};
+    GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_node_argmax, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_logits, ldl, (int)C, n_rows, d_nodes, m, d_out, bad);
+    int h_bad = 0;
+    GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    GNX_CHECK_ARG(h_bad == 0, "gnx_node_argmax: a node id is out of range");
+    return GNX_OK;
+}
+
+}  // extern "C"

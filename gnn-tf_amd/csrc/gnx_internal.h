@@ -120,6 +120,9 @@ struct SpmmArgs {
 };
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);
+// out[out_rows[r]] = act(X[in_rows[r]] . W + bias) on the matrix cores (gnx_dense.hip); row maps optional
+int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W, int64_t ldw, int64_t O, const float *bias, int act,
+               const int32_t *in_rows, const int32_t *out_rows, float *out, int64_t ldo, hipStream_t s);
 #ifdef GNX_TUNING
 extern int tune_override;
 #endif

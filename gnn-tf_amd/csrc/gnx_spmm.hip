@@ -260,6 +260,103 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
     }
 }
 
+// ---- GCNII layer: SpMM + mix + C x C transform on the matrix cores + activation, one launch ------------------------
+//   out[i,:] = act( (beta * sum_j A[i,j] X[j,:] + alpha * H0[i,:]) . M ),   M = (1-b) I + b W   (gcn.py:22-27)
+// A 512-thread block: every wave gathers a tile of 16 rows (4 NT lanes of float4 per row, U entries in flight per lane,
+// rows in degree-binned order), leaves the mixed rows in its LDS tile -- they never go to HBM -- multiplies the tile by
+// M (shared by the block in LDS, row stride = 4 mod 32 banks) with v_mfma_f32_16x16x4_f32 (exact f32), and stores whole
+// rows.  C = 16 NT for NT in {1, 2, 4}; rows longer than LONG_ROW are left to the long-row kernels + the dense kernel.
+template <int NT, int U, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const float *__restrict__ M, int64_t ldm) {
+    constexpr int C = 16 * NT, G = 4 * NT, RPP = 64 / G, PASSES = 16 / RPP, STRIDE = C + 4;
+    __shared__ float Ms[C * STRIDE];
+    __shared__ float Ts[WPB][16 * STRIDE];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int idx = threadIdx.x; idx < C * C; idx += 64 * WPB) Ms[(idx / C) * STRIDE + idx % C] = M[(int64_t)(idx / C) * ldm + idx % C];
+    __syncthreads();
+    const int64_t tile = (int64_t)blockIdx.x * WPB + wave;
+    if (tile * 16 >= p.n_rows) return;
+    float *__restrict__ T = Ts[wave];
+    const int sub = lane % G, c = sub * 4;
+    int64_t rows[PASSES];
+    bool live[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int rr = ps * RPP + lane / G;
+        const int64_t slot = tile * 16 + rr;
+        int64_t row = -1;
+        int64_t beg = 0, end = 0;
+        if (slot < p.n_rows) {
+            row = p.row_order ? (int64_t)p.row_order[slot] : slot;
+            beg = p.rowptr[row]; end = p.rowptr[row + 1];
+        }
+        live[ps] = row >= 0 && end - beg <= LONG_ROW;
+        rows[ps] = row;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live[ps]) {
+            const float *__restrict__ Xc = p.X + c;
+            for (int64_t e = beg; e < end; e += U) {
+                float x[U][4];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (e + u < end) {
+                        const int j = p.colidx[e + u];
+                        w[u] = p.vals[e + u];
+                        vload<4>(x[u], Xc + (int64_t)j * p.ldx);
+                    } else {
+                        w[u] = 0.f;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) x[u][v] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+            }
+            float h0[4];
+            vload<4>(h0, p.H0 + row * p.ldh0 + c);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = acc[v] * p.beta + h0[v] * p.alpha;      // filter.py:20-21 / gcn.py:25
+        }
+        vstore<4>(T + rr * STRIDE + c, acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // tile . M : A[m = lane & 15][k = 4 kk + (lane >> 4)] from the tile, B[k][n = lane & 15] from Ms
+    const int cc = lane & 15, g = lane >> 4;
+    f32x4 d[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) d[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = 0; kk < C / 4; ++kk) {
+        const float a = T[cc * STRIDE + 4 * kk + g];
+        const float *__restrict__ mrow = Ms + (4 * kk + g) * STRIDE + cc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, mrow[16 * nt], d[nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // D: lane (cc, g), register r -> row 4g + r, column 16 nt + cc; back through the tile so that rows leave as whole float4 rows
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = d[nt][r];
+            if (p.act == GNX_ACT_RELU) v = fmaxf(v, 0.f);
+            T[(4 * g + r) * STRIDE + 16 * nt + cc] = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        if (!live[ps]) continue;
+        const int rr = ps * RPP + lane / G;
+        float o[4];
+        vload<4>(o, T + rr * STRIDE + c);
+        vstore<4>(p.out + rows[ps] * p.ldo + c, o);
+    }
+}
+
 // ---- long rows ---------------------------------------------------------------------------------
 template <int VEC, int U>
 __global__ __launch_bounds__(256) void k_spmm_long_partial(const SpmmArgs p) {
@@ -595,6 +692,49 @@ int gnx_spmm_tv(gnx_graph_t g, const float *d_vals_t, const float *d_diag, const
     p.diag = d_diag; p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
     p.out = d_out; p.ldo = ldo; p.C = (int)C;
     return launch_spmm(g, g->t, p, s);
+}
+
+int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const float *d_H0, float a, int64_t C, const float *d_M,
+                   int64_t ldm, int act, float *d_out, float *d_work, void *stream) {
+    int rc = check_common("gnx_gcnii_step", g, d_H, C, C, d_H0, C, d_out, C);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_gcnii_step: invalid activation %d", act);
+    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols, "gnx_gcnii_step: needs a square graph");
+    GNX_CHECK_ARG(d_H0 != nullptr && d_M != nullptr && ldm >= C, "gnx_gcnii_step: NULL H0 / M or ldm < C");
+    hipStream_t s = (hipStream_t)stream;
+    const Csr &m = g->a;
+    const float beta = (float)(1.0 - (double)a);
+    const bool fusable = (C == 16 || C == 32 || C == 64) && aligned(d_H, 16) && aligned(d_H0, 16) && aligned(d_out, 16);
+    if (!fusable) {   // wide or odd widths: the fused SpMM+mix into the scratch, then the transform on the matrix cores
+        GNX_CHECK_ARG(d_work != nullptr && d_work != d_out && d_work != d_H, "gnx_gcnii_step: width %lld needs a distinct d_work [n, C]", (long long)C);
+        rc = gnx_spmm(g, d_vals, nullptr, d_H, C, C, d_H0, C, beta, a, GNX_ACT_NONE, d_work, C, stream);
+        if (rc != GNX_OK) return rc;
+        g->last_kernel = "spmm+dense_mfma";
+        return dense_rows(d_work, C, m.n_rows, C, d_M, ldm, C, nullptr, act, nullptr, nullptr, d_out, C, s);
+    }
+    if (m.n_rows == 0) return GNX_OK;
+    SpmmArgs p{};
+    p.vals = d_vals ? d_vals : g->raw_vals;
+    p.X = d_H; p.ldx = C; p.H0 = d_H0; p.ldh0 = C; p.beta = beta; p.alpha = a; p.act = act; p.out = d_out; p.ldo = C; p.C = (int)C;
+    p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.row_order = m.row_order;
+    p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
+    p.n_long = m.n_long; p.n_chunks = m.n_chunks;
+    const unsigned grid = blocks_for(blocks_for(m.n_rows, 16), 8);
+    if (C == 64)      hipLaunchKernelGGL((k_spmm_gcnii<4, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
+    else if (C == 32) hipLaunchKernelGGL((k_spmm_gcnii<2, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
+    else              hipLaunchKernelGGL((k_spmm_gcnii<1, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
+    g->last_kernel = "spmm_gcnii_mfma";
+    if (m.n_long > 0) {   // hub rows: chunked partial sums -> mixed rows written in place -> transform of those rows alone
+        rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float));
+        if (rc != GNX_OK) return rc;
+        p.partial = g->partial;
+        p.act = GNX_ACT_NONE;
+        launch_long<4>(p, s);
+        rc = dense_rows(d_out, C, m.n_long, C, d_M, ldm, C, nullptr, act, m.long_rows, m.long_rows, d_out, C, s);
+        if (rc != GNX_OK) return rc;
+    }
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
 }
 
 int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H, const float *d_H0, float a,

@@ -7,7 +7,8 @@ from .protocol import Layer, Layered
 from .blocks import Dense, Dropout, Activation, Branch, Resume, Concatenate, Tradeoff, relu, linear
 from .training import Predictor, Trainable
 from .tasks import NodeClassification
-from .sparse import SparseCOO, DeviceGraph, Adjacency, spmm, spmm_bias_act, ppr_step, ppr_loop, appnp_propagate, gather_rows, normalize, as_coo
+from .sparse import (SparseCOO, DeviceGraph, Adjacency, SparseRows, spmm, spmm_bias_act, ppr_step, ppr_loop, appnp_propagate, gather_rows, normalize,
+                     as_coo, dense, sparse_dense, gcnii_step, node_ce, node_argmax)
 from .graph_io import create_nx_graph, adj2graph, graph2indices, graph2adj
 from .graph_model import MLP, GNN, PPRIteration, PPRLoop, APPNP, GCNLayer, GCN, GCNIILayer, GCNII
 from .datasets import load_npz, save_npz

@@ -46,6 +46,14 @@ SIGNATURES = {
     "gnx_appnp_propagate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p]),
     "gnx_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gnx_gcnii_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_int64, c_int, c_void_p,
+                               c_void_p, c_void_p]),
+    "gnx_dense": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64,
+                          c_void_p]),
+    "gnx_node_ce": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "gnx_node_ce_backward": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                     c_void_p]),
+    "gnx_node_argmax": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "gnx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_graph_last_kernel": (c_char_p, [c_void_p]),
 }

@@ -1,13 +1,15 @@
 """Generic layers the propagation path plugs into: Dense, Dropout, Activation and the flow
 layers.  Mirrors reference gnntf/core/nn/layers.py:68-181 (the Keras adapter ``Wrap`` and
 the toy ``LSTM`` there are TensorFlow-specific / unused and are not part of this path).
-The dense transform is a plain library GEMM (rocBLAS through torch.matmul): MFMA work that
-is not on the measured path.
+On device tensors the dense transform runs on this repo's matrix-core kernel (gnx_dense, float32 MFMA); mostly-zero
+input features reach the first Dense as a device CSR and are transformed by the SpMM kernel instead (sparse.SparseRows).
+CPU tensors (host-logic tests of the protocol) use plain torch ops.
 """
 from __future__ import annotations
 
 import torch
 
+from . import sparse
 from .protocol import Layer, Layered
 
 
@@ -16,6 +18,20 @@ def linear(x):
 
 
 relu = torch.relu
+
+
+def affine(features, W, b, activation=linear):
+    """activation(features . W + b) -- layers.py:136.  Device tensors: gnx_dense (MFMA) with the bias and a relu fused;
+    SparseRows: the SpMM kernel over the rows of W; CPU tensors: torch."""
+    bias = b if isinstance(b, torch.Tensor) else None
+    fused_act = activation is relu or activation is linear
+    if isinstance(features, sparse.SparseRows):
+        out = sparse.sparse_dense(features, W, bias, relu=activation is relu)
+    elif features.is_cuda:
+        out = sparse.dense(features, W, bias, relu=activation is relu)
+    else:
+        return activation(torch.matmul(features, W) + b)
+    return out if fused_act else activation(out)
 
 
 class Dense(Layer):
@@ -32,7 +48,7 @@ class Dense(Layer):
         return (architecture.top_shape()[0], outputs)
 
     def __forward__(self, architecture: Layered, features):
-        return architecture.dropout(self.activation(torch.matmul(features, self.W) + self.b), self.dropout)
+        return architecture.dropout(affine(features, self.W, self.b, self.activation), self.dropout)
 
 
 class Dropout(Layer):

@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import sparse
-from .blocks import Dense, Dropout, linear, relu
+from .blocks import Dense, Dropout, affine, linear, relu
 from .params import default_device
 from .protocol import Layer
 from .training import Trainable
@@ -160,13 +160,14 @@ class GCNLayer(Layer):
         adjacency = gcn.get_adjacency(self.graph_dropout)
         if self.transform_first:
             bias = self.b if isinstance(self.b, torch.Tensor) else None
+            projected = affine(features, self.W, 0)
             if self.activation is relu or self.activation is linear:
-                out = sparse.spmm_bias_act(adjacency, torch.matmul(features, self.W), bias, relu=self.activation is relu)
+                out = sparse.spmm_bias_act(adjacency, projected, bias, relu=self.activation is relu)
             else:
-                out = self.activation(sparse.spmm_bias_act(adjacency, torch.matmul(features, self.W), bias))
+                out = self.activation(sparse.spmm_bias_act(adjacency, projected, bias))
             return gcn.dropout(out, self.dropout)
         aggregated_features = sparse.spmm(adjacency, features)
-        return gcn.dropout(self.activation(torch.matmul(aggregated_features, self.W) + self.b), self.dropout)
+        return gcn.dropout(affine(aggregated_features, self.W, self.b, self.activation), self.dropout)
 
 
 class GCN(GNN):
@@ -182,8 +183,9 @@ class GCN(GNN):
 
 class GCNIILayer(Layer):
     """gcn.py:7-27: dropout(act(((1-a) A.H + a H0) . ((1-b) I + b W))), b = beta_transformer(l / (k+1)).
-    The propagation and the (1-a)/a mix are the same fused kernel as PPRIteration; the C x C
-    transform that follows is a dense library GEMM."""
+    Inference: ONE launch per layer for C in {16, 32, 64} -- the mixed rows stay in LDS and meet (1-b) I + b W on the
+    matrix cores before the only store (gnx_gcnii_step); training keeps the mixed rows (dW needs them) and runs the
+    transform as its own matrix-core launch."""
 
     def __build__(self, architecture, H0: Layer, a: float, l: float, k: int = 0, activation=linear,
                   beta_transformer=math.log1p, dropout: float = 0.5, graph_dropout: float = 0.5, regularization=True):
@@ -199,9 +201,15 @@ class GCNIILayer(Layer):
 
     def __forward__(self, gcn, features):
         b = self.beta_transformer(self.l / (self.k + 1))
-        tradeoff = sparse.ppr_step(gcn.get_adjacency(self.graph_dropout), features, self.H0.value, self.a)
         eye = torch.eye(self.W.shape[1], device=self.W.device, dtype=self.W.dtype)
-        return gcn.dropout(self.activation(torch.matmul(tradeoff, (1 - b) * eye + b * self.W)), self.dropout)
+        transform = (1 - b) * eye + b * self.W
+        adjacency = gcn.get_adjacency(self.graph_dropout)
+        if features.is_cuda and adjacency.diag is None:
+            fused_act = self.activation is relu or self.activation is linear
+            out = sparse.gcnii_step(adjacency, features, self.H0.value, self.a, transform, relu=self.activation is relu)
+            return gcn.dropout(out if fused_act else self.activation(out), self.dropout)
+        tradeoff = sparse.ppr_step(adjacency, features, self.H0.value, self.a)
+        return gcn.dropout(self.activation(torch.matmul(tradeoff, transform)), self.dropout)
 
 
 class GCNII(GNN):

@@ -109,6 +109,9 @@ class Layered(VariableGenerator):
         """tf.nn.dropout(features, rate) while training, identity otherwise (layered.py:44-45)."""
         if not self._training or dropout == 0:
             return features
+        from .sparse import SparseRows
+        if isinstance(features, SparseRows):            # mostly-zero input features: drop stored entries (zeros stay zero either way)
+            return features.with_dropout(float(dropout), *self._next_mask_stream())
         return torch.nn.functional.dropout(features, p=float(dropout), training=True)
 
     def sparse_dropout(self, G, dropout=0.5):

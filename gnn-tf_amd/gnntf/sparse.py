@@ -361,3 +361,175 @@ def gather_rows(X: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         nat.check(nat.lib().gnx_gather_rows(nat.ptr(X), X.stride(0), nat.ptr(idx), idx.numel(), X.shape[1], nat.ptr(out),
                                             out.stride(0), nat.current_stream()))
     return out
+
+
+# ---- the dense ends of the path: matrix-core kernels of libgnx.so (csrc/gnx_dense.hip) ----------------------------------
+def _dense_launch(X, W, bias, relu):
+    nat.require_cuda(X, W, bias)
+    X, W = _as_f32_rows(X), _as_f32_rows(W)
+    if X.shape[1] != W.shape[0]:
+        raise Exception(f"dense: features have {X.shape[1]} columns, the weights expect {W.shape[0]}")
+    out = torch.empty((X.shape[0], W.shape[1]), dtype=torch.float32, device=X.device)
+    b = None if bias is None else bias.to(torch.float32).reshape(-1).contiguous()
+    if b is not None and b.numel() != W.shape[1]:
+        raise Exception("dense: bias width mismatch")
+    with torch.cuda.device(X.device):
+        nat.check(nat.lib().gnx_dense(nat.ptr(X), X.stride(0), X.shape[0], X.shape[1], nat.ptr(W), W.stride(0), W.shape[1], nat.ptr(b),
+                                      nat.ACT_RELU if relu else nat.ACT_NONE, nat.ptr(out), out.stride(0), nat.current_stream()))
+    return out
+
+
+class _DenseAct(torch.autograd.Function):
+    """out = act(X . W + b) on the matrix cores (layers.py:135-136; the transform of gcn.py:89).
+    backward: g' = g * (out > 0); dX = g' . W^T through the same kernel; dW = X^T . g' and db = column sums of g' are
+    reductions over the N rows, left to the library GEMM / a torch reduction (they are not on the forward path)."""
+
+    @staticmethod
+    def forward(ctx, X, W, bias, relu):
+        out = _dense_launch(X, W, bias, relu)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        ctx.bias_shape = None if bias is None else tuple(bias.shape)
+        ctx.save_for_backward(X, W, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, W, out = ctx.saved_tensors
+        g = (g * (out > 0)) if ctx.relu else g
+        g = g.contiguous()
+        gX = _dense_launch(g, W.t().contiguous(), None, False) if ctx.needs_input_grad[0] else None
+        gW = torch.matmul(X.t(), g) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=0).reshape(ctx.bias_shape) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gX, gW, gb, None
+
+
+def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False) -> torch.Tensor:
+    """act(X . W + bias) for device tensors, through gnx_dense (float32 MFMA).  ``bias`` [1, O] / [O] or None."""
+    return _DenseAct.apply(X, W, bias, bool(relu))
+
+
+def gcnii_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a: float, M: torch.Tensor, relu=True) -> torch.Tensor:
+    """act(((A . H)(1-a) + H0 a) . M), M = (1-b) I + b W (gcn.py:22-27).  Without autograd (inference) this is ONE fused
+    launch -- the mixed rows never reach HBM (gnx_gcnii_step); when gradients are needed the mixed rows must exist for
+    dM = T^T g, so the step runs as the fused SpMM+mix followed by the matrix-core transform."""
+    if torch.is_grad_enabled() and (H.requires_grad or H0.requires_grad or M.requires_grad):
+        return dense(ppr_step(adj, H, H0, a), M, None, relu)
+    g = adj.graph
+    nat.require_cuda(H, H0, M)
+    H, H0, M = _as_f32_rows(H).contiguous(), _as_f32_rows(H0).contiguous(), _as_f32_rows(M)
+    C = H.shape[1]
+    if g.n_rows != g.n_cols or H.shape[0] != g.n_rows or tuple(H0.shape) != tuple(H.shape) or tuple(M.shape) != (C, C):
+        raise Exception("gcnii_step: shape mismatch")
+    if adj.diag is not None:
+        raise Exception("gcnii_step: add_eye adjacencies are not supported by the fused step")
+    out = torch.empty_like(H)
+    work = None if C in (16, 32, 64) else torch.empty_like(H)
+    with torch.cuda.device(H.device):
+        nat.check(nat.lib().gnx_gcnii_step(g.handle, nat.ptr(adj.vals), nat.ptr(H), nat.ptr(H0), float(a), C, nat.ptr(M), M.stride(0),
+                                           nat.ACT_RELU if relu else nat.ACT_NONE, nat.ptr(out), nat.ptr(work), nat.current_stream()))
+    return out
+
+
+def _index64(x, device):
+    return torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.int64).to(device).contiguous()
+
+
+class _NodeCE(torch.autograd.Function):
+    """mean_i CE(log_softmax(logits[nodes_i]), labels_i) fused over the listed nodes (graph_predictor.py:19-25)."""
+
+    @staticmethod
+    def forward(ctx, logits, nodes, labels):
+        logits = _as_f32_rows(logits)
+        m = nodes.numel()
+        per_node = torch.empty(m, dtype=torch.float32, device=logits.device)
+        mean = torch.empty(1, dtype=torch.float32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            nat.check(nat.lib().gnx_node_ce(nat.ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], nat.ptr(nodes),
+                                            nat.ptr(labels), m, nat.ptr(per_node), nat.ptr(mean), nat.current_stream()))
+        ctx.save_for_backward(logits, nodes, labels)
+        return mean.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, nodes, labels = ctx.saved_tensors
+        grad = torch.zeros((logits.shape[0], logits.shape[1]), dtype=torch.float32, device=logits.device)
+        g = g.to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(logits.device):
+            nat.check(nat.lib().gnx_node_ce_backward(nat.ptr(logits), logits.stride(0), logits.shape[1], nat.ptr(nodes), nat.ptr(labels),
+                                                     nodes.numel(), nat.ptr(g), nat.ptr(grad), grad.stride(0), nat.current_stream()))
+        return grad, None, None
+
+
+def node_ce(logits: torch.Tensor, nodes, labels) -> torch.Tensor:
+    """The NodeClassification loss on the device in two small launches (gather + log-softmax + CE, then the mean)."""
+    nat.require_cuda(logits)
+    nodes, labels = _index64(nodes, logits.device), _index64(labels, logits.device)
+    if nodes.numel() != labels.numel() or nodes.numel() == 0:
+        raise Exception("node_ce: nodes and labels must be equally long and non-empty")
+    return _NodeCE.apply(logits, nodes, labels)
+
+
+def node_argmax(logits: torch.Tensor, nodes=None) -> torch.Tensor:
+    """argmax over the rows of ``nodes`` (all rows when None) in one launch; ties go to the lowest class."""
+    nat.require_cuda(logits)
+    logits = _as_f32_rows(logits.detach())
+    idx = None if nodes is None else _index64(nodes, logits.device)
+    m = logits.shape[0] if idx is None else idx.numel()
+    out = torch.empty(m, dtype=torch.int64, device=logits.device)
+    with torch.cuda.device(logits.device):
+        nat.check(nat.lib().gnx_node_argmax(nat.ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], nat.ptr(idx), m,
+                                            nat.ptr(out), nat.current_stream()))
+    return out
+
+
+# ---- sparse input features: the first Dense of the pre-MLP as an SpMM over the rows of W ---------------------------------
+class SparseRows:
+    """A feature matrix that is mostly zeros (Cora: 1433 columns, 1.3 % non-zero), held as a device CSR.  It flows through
+    the layer stack in place of the dense tensor until the first Dense consumes it: Dropout on it drops stored entries
+    (tf.nn.dropout leaves zeros zero, layers.py:180-181), Dense on it is X . W computed as an SpMM whose "dense operand" is
+    W -- 4F bytes of X per row become 8 bytes per stored entry, and W (F x 64 floats) stays cache resident."""
+
+    def __init__(self, graph: DeviceGraph, dropout=0.0, seed=0, stream_id=0):
+        self.graph, self.p, self.seed, self.stream_id = graph, float(dropout), int(seed), int(stream_id)
+        self.shape = (graph.n_rows, graph.n_cols)
+
+    @classmethod
+    def from_dense(cls, X: torch.Tensor):
+        idx = torch.nonzero(X)
+        return cls(DeviceGraph(SparseCOO(idx, X[idx[:, 0], idx[:, 1]], tuple(X.shape)), device=X.device))
+
+    def with_dropout(self, p, seed, stream_id):
+        if self.p != 0:
+            raise Exception("SparseRows: dropout applied twice before a Dense layer")
+        return SparseRows(self.graph, p, seed, stream_id)
+
+    def adjacency(self) -> Adjacency:
+        """The stored values (dropped per entry and rescaled while a dropout is pending) as an Adjacency over X."""
+        if self.p == 0:
+            return Adjacency(self.graph, None)
+        return normalize(self.graph, "none", "none", self.p, self.seed, self.stream_id)
+
+
+class _SparseDense(torch.autograd.Function):
+    """out = act(X . W + b), X sparse: forward = fused SpMM (bias through the H0 operand, relu in the epilogue);
+    backward dW = X^T . g' = the transposed SpMM; X is an input and gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, W, bias, adj, relu):
+        out = _launch(adj, W, bias, 1.0, 1.0, nat.ACT_RELU if relu else nat.ACT_NONE)
+        ctx.adj, ctx.relu, ctx.has_bias = adj, relu, bias is not None
+        ctx.save_for_backward(out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        g = ((g * (out > 0)) if ctx.relu else g).contiguous()
+        gW = _launch(ctx.adj, g, None, 1.0, 0.0, nat.ACT_NONE, transposed=True) if ctx.needs_input_grad[0] else None
+        gb = g.sum(dim=0, keepdim=True) if ctx.has_bias and ctx.needs_input_grad[1] else None
+        return gW, gb, None, None
+
+
+def sparse_dense(rows: SparseRows, W: torch.Tensor, bias=None, relu=False) -> torch.Tensor:
+    """act(X . W + bias) for sparse X (``bias`` [1, O] or None)."""
+    return _SparseDense.apply(W, bias, rows.adjacency(), bool(relu))

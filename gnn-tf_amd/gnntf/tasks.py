@@ -6,6 +6,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import sparse
 from .training import Predictor
 
 
@@ -20,7 +21,9 @@ class NodeClassification(Predictor):
         self.loss_transform = loss_transform
 
     def predict(self, features):
-        """argmax over the rows of ``nodes`` (graph_predictor.py:16-17)."""
+        """argmax over the rows of ``nodes`` (graph_predictor.py:16-17); on the device one fused gather+argmax launch."""
+        if features.is_cuda:
+            return sparse.node_argmax(features, self.nodes)
         return torch.argmax(features[_index(self.nodes, features.device)], dim=1)
 
     def loss(self, features):
@@ -28,6 +31,8 @@ class NodeClassification(Predictor):
             raise Exception("Evaluation requires node labels")
         if self.loss_transform is not None:
             features = self.loss_transform(features)
+        if features.is_cuda:          # gather + log-softmax + cross entropy fused (gnx_node_ce)
+            return sparse.node_ce(features, self.nodes, self.labels)
         predictions = torch.log_softmax(features[_index(self.nodes, features.device)], dim=1)
         # SparseCategoricalCrossentropy(from_logits=True) on top of the log-softmax (graph_predictor.py:24-25)
         return torch.nn.functional.cross_entropy(predictions, _index(self.labels, features.device))
@@ -35,6 +40,6 @@ class NodeClassification(Predictor):
     def evaluate(self, features):
         if self.labels is None:
             raise Exception("Evaluation requires node labels")
-        predictions = torch.argmax(features[_index(self.nodes, features.device)], dim=1)
+        predictions = self.predict(features)
         wrong = torch.count_nonzero(predictions - _index(self.labels, features.device)).item()
         return 1 - wrong / predictions.shape[0]

@@ -87,11 +87,32 @@ class _BestSoFar:
 
 
 class Trainable(Layered):
+    SPARSE_FEATURES_BELOW = 0.05        # input features with a smaller share of non-zeros reach the first Dense as a device CSR
+
     def __init__(self, features):
         features = _as_features(features)
         super().__init__(tuple(features.shape))
         self.features = features
         self._fast_predict = None
+        self._sparse_rows = None        # built on first use (device features only)
+
+    def __call__(self, features):
+        if features is self.features:
+            features = self._input_features()
+        return super().__call__(features)
+
+    def _input_features(self):
+        """self.features, or its SparseRows form when it is mostly zeros, lives on the device and the stack starts with
+        [Dropout]* Dense (the pre-MLP of filter.py:30-33) -- the only layers that know what to do with it."""
+        from .blocks import Dense, Dropout
+        from .sparse import SparseRows
+        X = self.features
+        if self._sparse_rows is None:
+            head = [layer for layer in self.layers() if not isinstance(layer, Dropout)]
+            eligible = (X.is_cuda and X.dim() == 2 and X.numel() > 0 and head and type(head[0]) is Dense
+                        and float(torch.count_nonzero(X)) < self.SPARSE_FEATURES_BELOW * X.numel())
+            self._sparse_rows = SparseRows.from_dense(X) if eligible else False
+        return self._sparse_rows if self._sparse_rows is not False else X
 
     def reset(self):
         super().reset()

@@ -165,6 +165,36 @@ int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const 
 int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0,
                         float a, int K, int64_t C, float *d_out, float *d_work, void *stream);
 
+/* One GCNIILayer.__forward__ (gnntf/core/gnn/architectures/gcn.py:22-27) with a fixed adjacency:
+ *   out = act( ((A_hat . H)*(1-a) + H0*a) . M ),   M = (1-b) I + b W  given by the caller as a [C, C] matrix (ldm).
+ * For C in {16, 32, 64} (16-byte aligned buffers) this is ONE launch for all rows of at most 512 entries: the mixed rows
+ * stay in LDS and meet M on the matrix cores (v_mfma_f32_16x16x4_f32, exact float32) before the only store; hub rows go
+ * through the long-row kernels and the dense kernel.  Other widths run gnx_spmm into d_work [n, C] (must be given,
+ * distinct from d_out and d_H) and then gnx_dense.  All matrices contiguous [n, C]; square graph. */
+int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const float *d_H0, float a, int64_t C,
+                   const float *d_M, int64_t ldm, int act, float *d_out, float *d_work, void *stream);
+
+/* ---- the dense ends of the path (matrix cores) -----------------------------------------------------------------------
+ * gnx_dense: out = act(X . W + bias) -- Dense.__forward__ (gnntf/core/nn/layers.py:135-136) and the transform of
+ * GCNLayer (gcn.py:89).  X [n, F] (ldx), W [F, O] (ldw), bias [O] or NULL, out [n, O] (ldo); float32 in and out, float32
+ * accumulate on v_mfma_f32_16x16x4_f32.  out must not alias X. */
+int gnx_dense(const float *d_X, int64_t ldx, int64_t n, int64_t F, const float *d_W, int64_t ldw, int64_t O,
+              const float *d_bias, int act, float *d_out, int64_t ldo, void *stream);
+
+/* The task head, NodeClassification (gnntf/core/gnn/graph_predictor.py:16-31), fused over the listed nodes:
+ * gnx_node_ce:      d_loss_per_node[i] = logsumexp(logits[nodes[i], :]) - logits[nodes[i], labels[i]] and their mean in
+ *                   d_mean_loss[0] (= SparseCategoricalCrossentropy(from_logits) of log_softmax, graph_predictor.py:24-25).
+ *                   Synchronises the stream (reports out-of-range node ids / labels as GNX_ERR_INVALID).
+ * gnx_node_ce_backward: d_grad_logits[nodes[i], :] += d_grad_loss[0] / m * (softmax(logits[nodes[i], :]) - onehot(labels[i]));
+ *                   the caller zero-fills d_grad_logits [n_rows, C] first.
+ * gnx_node_argmax:  d_out[i] = first index of the maximum of logits[nodes[i], :] (d_nodes NULL: row i); graph_predictor.py:17. */
+int gnx_node_ce(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes,
+                const int64_t *d_labels, int64_t m, float *d_loss_per_node, float *d_mean_loss, void *stream);
+int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t C, const int64_t *d_nodes, const int64_t *d_labels,
+                         int64_t m, const float *d_grad_loss, float *d_grad_logits, int64_t ldg, void *stream);
+int gnx_node_argmax(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, int64_t m,
+                    int64_t *d_out, void *stream);
+
 /* Halo packing for the vertex-partitioned path: out[r,:] = X[idx[r],:], idx int64 [n_idx]. */
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,
                     float *d_out, int64_t ldo, void *stream);

@@ -1,0 +1,179 @@
+"""The dense ends of the path on the matrix cores (csrc/gnx_dense.hip, k_spmm_gcnii) against float64 numpy / the oracle:
+Dense (layers.py:135-136), the GCNII layer (gcn.py:22-27), the NodeClassification head (graph_predictor.py:16-31) and the
+sparse-input form of the first Dense.  float32 tolerance of BASELINE.json: rtol 1e-4 (+ atol for sums that cancel)."""
+import numpy as np
+import pytest
+import torch
+
+import graphs
+from oracle import gnntf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 1e-5
+
+
+@pytest.fixture(scope="module")
+def gnntf():
+    import gnntf
+    gnntf.set_default_device("cuda:0")
+    yield gnntf
+    gnntf.set_default_device(None)
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("n,F,O", [(1, 1, 1), (100, 7, 3), (1000, 128, 64), (513, 1433, 64), (300, 64, 40), (2049, 64, 7), (257, 100, 300),
+                                   (64, 16, 16), (130, 257, 129), (4097, 512, 256)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_dense_mfma_matches_float64(gnntf, n, F, O, relu):
+    rng = np.random.default_rng(n + F + O)
+    X, W, b = rng.standard_normal((n, F)).astype(np.float32), rng.standard_normal((F, O)).astype(np.float32), rng.standard_normal((1, O)).astype(np.float32)
+    got = gnntf.dense(dev(X), dev(W), dev(b), relu=relu).cpu().numpy()
+    want = X.astype(np.float64) @ W.astype(np.float64) + b
+    want = np.maximum(want, 0) if relu else want
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4 * np.sqrt(F))
+
+
+def test_dense_mfma_layout_and_strides(gnntf):
+    """A = I with an ASYMMETRIC W catches a transposed fragment map; strided / unaligned operands take the scalar-load path."""
+    W = (np.arange(48 * 40, dtype=np.float32).reshape(48, 40) * 0.5 - 7)          # W[i][j] != W[j][i]
+    eye = np.eye(48, dtype=np.float32)
+    np.testing.assert_array_equal(gnntf.dense(dev(eye), dev(W)).cpu().numpy(), W)  # exact: one non-zero product per output
+    rng = np.random.default_rng(0)
+    big = dev(rng.standard_normal((300, 131)).astype(np.float32))
+    Xv = big[:, 3:100]                                                              # ld 131, offset 3: not 16-byte aligned
+    Wbig = dev(rng.standard_normal((97, 70)).astype(np.float32))
+    Wv = Wbig[:, 5:55]                                                              # ldw 70
+    got = gnntf.dense(Xv, Wv, None).cpu().numpy()
+    want = Xv.cpu().numpy().astype(np.float64) @ Wv.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-3)
+    with pytest.raises(Exception, match="expect"):
+        gnntf.dense(dev(eye), dev(W[:40]))
+    with pytest.raises(Exception, match="no CPU fallback"):
+        gnntf.dense(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_dense_backward(gnntf):
+    rng = np.random.default_rng(3)
+    X, W, b = (rng.standard_normal(s).astype(np.float32) for s in ((500, 96), (96, 48), (1, 48)))
+    gout = rng.standard_normal((500, 48)).astype(np.float32)
+    grads = []
+    for ours in (True, False):
+        Xt, Wt, bt = (dev(t).requires_grad_() for t in (X, W, b))
+        out = gnntf.dense(Xt, Wt, bt, relu=True) if ours else torch.relu(Xt @ Wt + bt)
+        out.backward(dev(gout))
+        grads.append([t.grad.cpu().numpy() for t in (Xt, Wt, bt)])
+    for a, w in zip(*grads):
+        np.testing.assert_allclose(a, w, rtol=1e-3, atol=1e-3)
+
+
+def hub_graph(n, m, hub_entries, seed):
+    """An R-MAT graph plus one hub row/column with more than LONG_ROW (512) entries."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, m, seed=seed)
+    others = np.random.default_rng(seed).choice(np.arange(1, n), size=hub_entries, replace=False)
+    extra = np.concatenate([np.stack([np.zeros_like(others), others], 1), np.stack([others, np.zeros_like(others)], 1)])
+    coo = np.unique(np.concatenate([coo, extra]), axis=0)
+    return coo, np.ones(len(coo), dtype=np.float32), shape
+
+
+@pytest.mark.parametrize("C", [16, 32, 64, 48, 128])
+@pytest.mark.parametrize("relu", [True, False])
+def test_gcnii_step_fused(gnntf, C, relu):
+    """gcn.py:22-27 in one launch (C = 16/32/64: LDS tile + MFMA; hub rows through the long-row + dense kernels) or as
+    SpMM + dense (other widths), against the oracle's float64 arithmetic."""
+    n = 3000
+    coo, vals, shape = hub_graph(n, 20000, 900, seed=C)
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(coo, vals, shape), device="cuda:0")
+    adj = gnntf.normalize(g, "symmetric")
+    rng = np.random.default_rng(C)
+    H, H0 = rng.standard_normal((n, C)).astype(np.float32), rng.standard_normal((n, C)).astype(np.float32)
+    M = (0.6 * np.eye(C) + 0.4 * rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)
+    with torch.no_grad():
+        got = gnntf.gcnii_step(adj, dev(H), dev(H0), 0.1, dev(M), relu=relu).cpu().numpy()
+    ai, av = orc.get_adjacency(coo, vals, shape, dtype=np.float64)
+    want = orc.ppr_iteration(ai, av, shape, H.astype(np.float64), H0.astype(np.float64), 0.1) @ M.astype(np.float64)
+    want = np.maximum(want, 0) if relu else want
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4)
+    assert g.last_kernel() == ("spmm_gcnii_mfma" if C in (16, 32, 64) else "spmm+dense_mfma")
+    # with gradients the mixed rows are kept: same values through the two-launch form, and dM / dH / dH0 flow
+    Ht, H0t, Mt = dev(H).requires_grad_(), dev(H0).requires_grad_(), dev(M).requires_grad_()
+    out = gnntf.gcnii_step(adj, Ht, H0t, 0.1, Mt, relu=relu)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=RTOL, atol=1e-4)
+    out.sum().backward()
+    T = orc.ppr_iteration(ai, av, shape, H.astype(np.float64), H0.astype(np.float64), 0.1)
+    gate = (T @ M > 0) if relu else np.ones((n, C), dtype=bool)
+    np.testing.assert_allclose(Mt.grad.cpu().numpy(), T.T @ gate, rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(H0t.grad.cpu().numpy(), 0.1 * (gate @ M.T.astype(np.float64)), rtol=1e-3, atol=1e-4)
+
+
+def test_node_head(gnntf):
+    """gather + log-softmax + CE + mean, its backward, and gather + argmax (first maximum), against the oracle / torch."""
+    rng = np.random.default_rng(8)
+    for C in (1, 7, 16, 40, 129):
+        n, m = 2000, 700
+        logits = (rng.standard_normal((n, C)) * 3).astype(np.float32)
+        nodes = rng.integers(0, n, size=m)                                      # with repeats
+        labels = rng.integers(0, C, size=m)
+        L = dev(logits).requires_grad_()
+        loss = gnntf.node_ce(L, nodes, labels)
+        want = orc.node_loss(logits.astype(np.float64), nodes, labels)
+        assert abs(float(loss) - want) <= 1e-5 * max(abs(want), 1.0), (C, float(loss), want)
+        (loss * 1.7).backward()
+        Lt = dev(logits).requires_grad_()
+        (torch.nn.functional.cross_entropy(Lt[dev(nodes)], dev(labels)) * 1.7).backward()
+        np.testing.assert_allclose(L.grad.cpu().numpy(), Lt.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+        np.testing.assert_array_equal(gnntf.node_argmax(dev(logits), nodes).cpu().numpy(), orc.node_predict(logits, nodes))
+        np.testing.assert_array_equal(gnntf.node_argmax(dev(logits)).cpu().numpy(), logits.argmax(1))
+    ties = np.zeros((5, 9), dtype=np.float32); ties[1, 3] = ties[1, 7] = 2.0; ties[2, 8] = 1.0
+    assert gnntf.node_argmax(dev(ties)).cpu().numpy().tolist() == [0, 3, 8, 0, 0]
+    with pytest.raises(Exception, match="out of range"):
+        gnntf.node_ce(dev(logits), [0, n], [0, 0])
+    with pytest.raises(Exception, match="out of range"):
+        gnntf.node_ce(dev(logits), [0, 1], [0, 129])
+    with pytest.raises(Exception, match="out of range"):
+        gnntf.node_argmax(dev(logits), [-1])
+    # through the task API (graph_predictor.py:10-31)
+    task = gnntf.NodeClassification(list(range(50)), labels[:50] % 7)
+    small = dev(logits[:, :7].copy())
+    assert abs(float(task.loss(small)) - orc.node_loss(logits[:, :7].astype(np.float64), np.arange(50), labels[:50] % 7)) < 1e-5
+    assert task.predict(small).cpu().numpy().tolist() == logits[:50, :7].argmax(1).tolist()
+    assert abs(task.evaluate(small) - orc.node_evaluate(logits[:, :7], np.arange(50), labels[:50] % 7)) < 1e-12
+
+
+def test_sparse_input_features(gnntf):
+    """Mostly-zero input features (Cora-shaped: 1433 columns, 1.3 % non-zero) reach the first Dense as a device CSR:
+    X . W through the SpMM kernel == the dense product; dropout on them drops stored entries with the counter RNG."""
+    coo, vals, shape, X = graphs.cora_shaped(seed=0)
+    rng = np.random.default_rng(1)
+    W, b = rng.standard_normal((X.shape[1], 64)).astype(np.float32), rng.standard_normal((1, 64)).astype(np.float32)
+    rows = gnntf.SparseRows.from_dense(dev(X))
+    assert rows.graph.nnz == np.count_nonzero(X) and rows.shape == X.shape
+    want = np.maximum(X.astype(np.float64) @ W + b, 0)
+    Wt, bt = dev(W).requires_grad_(), dev(b).requires_grad_()
+    out = gnntf.sparse_dense(rows, Wt, bt, relu=True)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    gout = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(gout))
+    gate = gout * (want > 0)
+    np.testing.assert_allclose(Wt.grad.cpu().numpy(), X.T.astype(np.float64) @ gate, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(bt.grad.cpu().numpy(), gate.sum(0, keepdims=True), rtol=1e-3, atol=1e-3)
+    # a pending dropout: exactly the oracle's keep mask over X's stored entries (row-major order of np.nonzero)
+    xi = np.stack(np.nonzero(X), 1)
+    keep = orc.keep_mask(xi, 0.5, 77, 3)
+    Xd = np.zeros_like(X); Xd[xi[keep, 0], xi[keep, 1]] = X[xi[keep, 0], xi[keep, 1]] * 2
+    dropped = gnntf.sparse_dense(rows.with_dropout(0.5, 77, 3), dev(W), None).cpu().numpy()
+    np.testing.assert_allclose(dropped, Xd.astype(np.float64) @ W, rtol=RTOL, atol=ATOL)
+    assert 0.4 < keep.mean() < 0.6
+    # the model picks the sparse form by itself (APPNP: Dropout -> Dense ...), a GCN (SpMM first) does not
+    model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7)
+    assert isinstance(model._input_features(), gnntf.SparseRows)
+    gcn = gnntf.GCN(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7)
+    assert gcn._input_features() is gcn.features
+    model.reset()
+    with model:                                                                # training mode: input dropout on the stored entries
+        a = model(model.features)
+    assert a.shape == (shape[0], 7) and bool(torch.isfinite(a).all())
+    dense_X = rng.standard_normal((shape[0], 30)).astype(np.float32)
+    assert gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), dense_X, num_classes=7)._input_features().__class__ is torch.Tensor
