@@ -91,6 +91,37 @@ void free_csr(Csr &m);
 int ensure_transpose(gnx_graph *g, hipStream_t s);
 int ensure_partial(gnx_graph *g, size_t bytes);
 
+// ---- counter RNG of the edge dropout: the same integer arithmetic as oracle/gnntf_oracle.py:hash_u24 ----------
+__device__ __forceinline__ uint64_t rng_fin(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint32_t hash_u24(uint64_t seed, uint64_t stream, uint64_t row, uint64_t col, uint64_t dup) {
+    const uint64_t k = seed ^ (stream * 0xD1342543DE82EF95ull);
+    uint64_t x = rng_fin(k + row * 0x9E3779B97F4A7C15ull);
+    x ^= col * 0xC2B2AE3D27D4EB4Full;
+    x = rng_fin(x + dup * 0x165667B19E3779F9ull);
+    return (uint32_t)(x >> 40);
+}
+
+// gnx_spmm_dropped: the values of one training iteration's dropped + re-normalised adjacency are produced inside the
+// SpMM, per entry, with exactly the arithmetic of k_scale_values (gnx_prep.hip): (D[row] * drop(raw)) * D[col].
+struct DropFuse {
+    const float *D;        // degree scales of this (seed, stream); null = not fused
+    uint64_t seed, stream;
+    uint32_t thr;          // keep iff hash >= thr
+    float scale;           // 1 / (1 - p)
+    int transposed;        // the structure walked is the transpose: its entry (r, c) is A[c][r]
+};
+
+__device__ __forceinline__ float dropped_weight(const DropFuse &f, float raw, int64_t r, int64_t c) {
+    const int64_t ar = f.transposed ? c : r, ac = f.transposed ? r : c;      // the entry's (row, col) in A
+    const float v = hash_u24(f.seed, f.stream, (uint64_t)ar, (uint64_t)ac, 0) >= f.thr ? raw * f.scale : 0.f;
+    return (f.D[ar] * v) * f.D[ac];
+}
+
 struct SpmmArgs {
     const int64_t *rowptr;
     const int32_t *colidx;
@@ -117,6 +148,7 @@ struct SpmmArgs {
     float *partial;
     int64_t n_long, n_chunks;
     int tune;
+    DropFuse fuse;
 };
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);

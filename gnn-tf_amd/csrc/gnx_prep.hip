@@ -10,21 +10,6 @@ namespace {
 
 inline unsigned blocks_for(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
-// ---- counter RNG: the same integer arithmetic as oracle/gnntf_oracle.py:hash_u24 ----------
-__device__ __forceinline__ uint64_t fin(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
-__device__ __forceinline__ uint32_t hash_u24(uint64_t seed, uint64_t stream, uint64_t row, uint64_t col, uint64_t dup) {
-    const uint64_t k = seed ^ (stream * 0xD1342543DE82EF95ull);
-    uint64_t x = fin(k + row * 0x9E3779B97F4A7C15ull);
-    x ^= col * 0xC2B2AE3D27D4EB4Full;
-    x = fin(x + dup * 0x165667B19E3779F9ull);
-    return (uint32_t)(x >> 40);
-}
-
 struct Drop {
     uint64_t seed, stream;
     uint32_t thr;    // keep iff hash >= thr

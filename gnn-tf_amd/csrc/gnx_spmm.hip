@@ -76,10 +76,11 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 
 // Sum of w_e * X[col_e, c .. c+VEC) over entries [beg, end) of one row; the whole wave works
 // on the same entries (beg/end wave-uniform), lane `lane` owns columns c .. c+VEC.
-template <int VEC, int U>
+template <int VEC, int U, bool FUSE = false>
 __device__ __forceinline__ void wave_accumulate(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
                                                 const float *__restrict__ X, int64_t ldx, int64_t beg, int64_t end,
-                                                int c, int lane, float (&acc)[VEC], bool nt_index = false) {
+                                                int c, int lane, float (&acc)[VEC], bool nt_index = false,
+                                                const DropFuse *fuse = nullptr, int64_t row = 0) {
     for (int64_t base = beg; base < end; base += 64) {
         const int n = (int)((end - base) < 64 ? (end - base) : 64);
         int mycol = 0;
@@ -92,6 +93,7 @@ __device__ __forceinline__ void wave_accumulate(const int32_t *__restrict__ coli
                 mycol = colidx[base + lane];
                 myval = vals[base + lane];
             }
+            if (FUSE) myval = dropped_weight(*fuse, myval, row, mycol);      // one entry per lane: 64 weights per wave instruction
         }
         int i = 0;
         for (; i + U <= n; i += U) {
@@ -457,6 +459,160 @@ __global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs p) {
     }
 }
 
+// ---- training iterations: the dropped + re-normalised values are produced inside the SpMM (gnx_spmm_dropped) ------------
+// Same row / lane mapping as the kernels above; what differs is where an entry's weight comes from: p.vals holds the RAW
+// values and every weight is (D[row] * drop(raw)) * D[col] (layered.py:47-50 + gnn.py:41-42), computed ONCE per entry by one
+// lane and handed to the lanes that need it (readlane / shuffles), so the hash costs one evaluation per stored entry.
+template <int VEC, int U, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_spmm_wave_drop(const SpmmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t row = (int64_t)blockIdx.x * WPB + wib;
+    if (row >= p.n_rows) return;
+    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    if (end - beg > LONG_ROW) return;
+    for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
+        const int c = c0 + lane * VEC;
+        const bool active = c < p.C;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        wave_accumulate<VEC, U, true>(p.colidx, p.vals, p.X, p.ldx, beg, end, active ? c : 0, lane, acc, false, &p.fuse, row);
+        epilogue_store<VEC>(p, row, c, active, acc);
+    }
+}
+
+template <int VEC, int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int64_t slot = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+    if (slot >= p.n_rows) return;
+    const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
+    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    if (end - beg > LONG_ROW) return;
+    for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
+        const int c = c0 + sub * VEC;
+        const bool active = c < p.C;
+        const float *__restrict__ Xc = p.X + (active ? c : 0);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int64_t base = beg; base < end; base += G) {          // G entries per round: lane `sub` owns entry base + sub
+            const int n = (int)((end - base) < G ? (end - base) : G);
+            int mycol = 0;
+            float myw = 0.f;
+            if (sub < n) {
+                mycol = p.colidx[base + sub];
+                myw = dropped_weight(p.fuse, p.vals[base + sub], row, mycol);
+            }
+            for (int i = 0; i < n; i += U) {
+                float x[U][VEC];
+                float w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = __shfl(mycol, i + u, G);
+                    w[u] = __shfl(myw, i + u, G);
+                    if (i + u < n) vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                    else {
+                        w[u] = 0.f;
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+            }
+        }
+        epilogue_store<VEC>(p, row, c, active, acc);
+    }
+}
+
+template <int VEC, int U>
+__global__ __launch_bounds__(256) void k_spmm_long_partial_drop(const SpmmArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t cslot = (int64_t)blockIdx.x * 4 + wib;
+    if (cslot >= p.n_chunks) return;
+    const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;
+    const int32_t li = p.chunk_long[chunk];
+    const int64_t row = p.long_rows[li];
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t rend = p.rowptr[row + 1];
+    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
+        const int c = c0 + lane * VEC;
+        const bool active = c < p.C;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        wave_accumulate<VEC, U, true>(p.colidx, p.vals, p.X, p.ldx, beg, end, active ? c : 0, lane, acc, false, &p.fuse, row);
+        if (active) vstore<VEC>(p.partial + chunk * (int64_t)p.C + c, acc);
+    }
+}
+
+// narrow long rows: the wave computes 64 weights per round (one per lane); sub-group s then takes entries s, s + NS, ... of the
+// round, which is the entry -> sub-group dealing of k_spmm_long_partial_group (so the partial sums are bitwise the same)
+template <int VEC, int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_long_partial_group_drop(const SpmmArgs p) {
+    constexpr int NS = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t cslot = (int64_t)blockIdx.x * 4 + wib;
+    if (cslot >= p.n_chunks) return;
+    const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;
+    const int32_t li = p.chunk_long[chunk];
+    const int64_t row = p.long_rows[li];
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t rend = p.rowptr[row + 1];
+    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    const int sub = lane / G;
+    const int c = (lane % G) * VEC;
+    const bool active = c < p.C;
+    const float *__restrict__ Xc = p.X + (active ? c : 0);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    // the reference kernel walks e = beg + sub + k * NS (k = 0, 1, ...) in batches of U: entry index within the chunk = sub + k NS.
+    // A round of 64 entries covers k = 0 .. 64/NS - 1 = G - 1 for every sub-group.
+    for (int64_t base = beg; base < end; base += 64) {
+        const int n = (int)((end - base) < 64 ? (end - base) : 64);
+        int mycol = 0;
+        float myw = 0.f;
+        if (lane < n) {
+            mycol = p.colidx[base + lane];
+            myw = dropped_weight(p.fuse, p.vals[base + lane], row, mycol);
+        }
+        for (int k = 0; k < G; k += U) {
+            float x[U][VEC];
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int src = sub + (k + u) * NS;                  // entry of the round this sub-group takes in slot k + u
+                const int j = __shfl(mycol, src);
+                w[u] = __shfl(myw, src);
+                if (k + u < G && src < n) vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                else {
+                    w[u] = 0.f;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+        }
+    }
+#pragma unroll
+    for (int off = G; off < 64; off <<= 1)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
+    if (sub == 0 && active) vstore<VEC>(p.partial + chunk * (int64_t)p.C + c, acc);
+}
+
 // ---- small helpers --------------------------------------------------------------------------------
 __global__ void k_gather_vals(const float *__restrict__ vals, const int32_t *__restrict__ perm, int64_t n,
                               float *__restrict__ out) {
@@ -547,6 +703,32 @@ void launch_long(const SpmmArgs &p, hipStream_t s) {
     GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
 }
 
+template <int VEC>
+const char *launch_rows_drop(const SpmmArgs &p, hipStream_t s) {
+    const int lanes = (p.C + VEC - 1) / VEC;
+    if (lanes > 32) {
+        if (p.C <= 64 * VEC) hipLaunchKernelGGL((k_spmm_wave_drop<VEC, 8, 8>), dim3(blocks_for(p.n_rows, 8)), dim3(512), 0, s, p);
+        else                 hipLaunchKernelGGL((k_spmm_wave_drop<VEC, 8, 4>), dim3(blocks_for(p.n_rows, 4)), dim3(256), 0, s, p);
+        return "spmm_wave_drop";
+    }
+    if (lanes > 16) { GNX_LAUNCH((k_spmm_group_drop<VEC, 32, 4>), blocks_for(p.n_rows, 8), p); return "spmm_group32_drop"; }
+    if (lanes > 8)  { GNX_LAUNCH((k_spmm_group_drop<VEC, 16, 4>), blocks_for(p.n_rows, 16), p); return "spmm_group16_drop"; }
+    if (lanes > 4)  { GNX_LAUNCH((k_spmm_group_drop<VEC, 8, 4>), blocks_for(p.n_rows, 32), p); return "spmm_group8_drop"; }
+    GNX_LAUNCH((k_spmm_group_drop<VEC, 4, 4>), blocks_for(p.n_rows, 64), p);
+    return "spmm_group4_drop";
+}
+
+template <int VEC>
+void launch_long_drop(const SpmmArgs &p, hipStream_t s) {
+    const int lanes = (p.C + VEC - 1) / VEC;
+    if (lanes > 32)      GNX_LAUNCH((k_spmm_long_partial_drop<VEC, 8>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 16) GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 32, 4>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 8)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 16, 4>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 4)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 8, 4>), blocks_for(p.n_chunks, 4), p);
+    else                 GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 4, 4>), blocks_for(p.n_chunks, 4), p);
+    GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
+}
+
 int check_common(const char *fn, gnx_graph *g, const float *X, int64_t ldx, int64_t C, const float *H0, int64_t ldh0,
                  float *out, int64_t ldo) {
     GNX_CHECK_ARG(g != nullptr, "%s: NULL handle", fn);
@@ -588,6 +770,14 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     }
     const int vec = pick_vec(p);
     const char *name;
+    if (p.fuse.D != nullptr) {
+        if (vec == 4)      { name = launch_rows_drop<4>(p, s); if (m.n_long) launch_long_drop<4>(p, s); }
+        else if (vec == 2) { name = launch_rows_drop<2>(p, s); if (m.n_long) launch_long_drop<2>(p, s); }
+        else               { name = launch_rows_drop<1>(p, s); if (m.n_long) launch_long_drop<1>(p, s); }
+        g->last_kernel = name;
+        GNX_HIP(hipGetLastError());
+        return GNX_OK;
+    }
     if (vec == 4)      { name = launch_rows<4>(p, s); if (m.n_long) launch_long<4>(p, s); }
     else if (vec == 2) { name = launch_rows<2>(p, s); if (m.n_long) launch_long<2>(p, s); }
     else               { name = launch_rows<1>(p, s); if (m.n_long) launch_long<1>(p, s); }
@@ -662,6 +852,35 @@ int gnx_spmm_rows(gnx_graph_t g, const float *d_vals, const float *d_X, int64_t 
     p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
     p.out = d_out; p.ldo = ldo; p.C = (int)C; p.out_rows = d_rows; p.map_h0 = true;
     return launch_spmm(g, g->a, p, (hipStream_t)stream);
+}
+
+int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int transposed,
+                     const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
+                     float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm_dropped", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_dropped: invalid activation %d", act);
+    GNX_CHECK_ARG(d_D != nullptr, "gnx_spmm_dropped: NULL degree scales");
+    GNX_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout rate %g outside [0, 1)", (double)dropout_p);
+    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols, "gnx_spmm_dropped: needs a square graph");
+    if (g->has_dups) {   // per-entry dropout of duplicated COO entries needs the entry lists: use gnx_graph_normalize + gnx_spmm
+        set_error("gnx_spmm_dropped: the graph holds duplicate COO entries");
+        return GNX_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (transposed) {
+        rc = ensure_transpose(g, s);
+        if (rc != GNX_OK) return rc;
+    }
+    SpmmArgs p{};
+    p.vals = transposed ? g->t_raw : g->raw_vals;
+    p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C;
+    p.fuse.D = d_D; p.fuse.seed = seed; p.fuse.stream = stream_id;
+    p.fuse.thr = (uint32_t)((double)dropout_p * 16777216.0);
+    p.fuse.scale = 1.0f / (1.0f - dropout_p);
+    p.fuse.transposed = transposed ? 1 : 0;
+    return launch_spmm(g, transposed ? g->t : g->a, p, s);
 }
 
 int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream) {

@@ -37,6 +37,8 @@ SIGNATURES = {
                            c_int, c_void_p, c_int64, c_void_p]),
     "gnx_spmm_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,
                                  c_int, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gnx_spmm_dropped": (c_int, [c_void_p, c_void_p, c_float, c_uint64, c_uint64, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                 c_float, c_float, c_int, c_void_p, c_int64, c_void_p]),
     "gnx_spmm_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_int,
                               c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_spmm_tv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,

@@ -66,6 +66,8 @@ class GNN(Trainable):
             raise Exception("Invalid matrix normalization")
         if graph_dropout != 0 and self.is_training():
             seed, stream = self._next_mask_stream()
+            if normalized == "symmetric" and add_eye == "none":          # the values are produced inside the SpMM kernels
+                return sparse.dropped_adjacency(self.graph, graph_dropout, seed, stream)
             return sparse.normalize(self.graph, normalized, add_eye, graph_dropout, seed, stream)
         key = (normalized, add_eye)
         if key not in self._adjacency_cache:
@@ -112,7 +114,16 @@ class PPRLoop(Layer):
         if self.graph_dropout != 0 and architecture.is_training():
             seed, first = architecture._next_mask_stream(self.iterations)
             graph, p = architecture.graph, self.graph_dropout
-            make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
+            kept = dict()                                                  # the N degree scales of an iteration serve its backward too
+
+            def make_adj(k, bwd=False):
+                if k in kept:
+                    return kept.pop(k) if bwd else kept[k]
+                adj = sparse.dropped_adjacency(graph, p, seed, first + k)
+                if isinstance(adj, sparse.DroppedAdjacency):
+                    kept[k] = adj                                          # N floats: cheap to keep until the backward
+                    return adj
+                return sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=True) if bwd else adj
         else:
             adj = architecture.get_adjacency(self.graph_dropout)
             make_adj = lambda k, bwd=False: adj

@@ -136,6 +136,45 @@ class Adjacency:
         return (self.graph.n_rows, self.graph.n_cols)
 
 
+class DroppedAdjacency(Adjacency):
+    """The dropped + symmetrically re-normalised adjacency of one training iteration (layered.py:47-50 + gnn.py:41-42) WITHOUT
+    its nnz-sized value array: only the N degree scales are computed up front; the SpMM kernels produce every entry's weight
+    (D[row] * dropout(raw)) * D[col] from the counter RNG while they gather (gnx_spmm_dropped) -- forward and transposed, bit
+    for bit the values gnx_graph_normalize would have written.  ``.vals`` materialises them on demand (custom layers)."""
+
+    def __init__(self, graph: DeviceGraph, p, seed, stream_id):
+        super().__init__(graph, None, None, None)
+        self.p, self.seed, self.stream_id = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFFFFFFFFFF
+        self.D = torch.empty(graph.n_cols, dtype=torch.float32, device=graph.device)
+        with torch.cuda.device(graph.device):
+            nat.check(nat.lib().gnx_graph_colsum(graph.handle, self.p, self.seed, self.stream_id, nat.ptr(self.D), nat.current_stream()))
+            nat.check(nat.lib().gnx_degree_scale(nat.ptr(self.D), self.D.numel(), nat.NORM["symmetric"], 0, nat.current_stream()))
+        self._vals = None
+
+    @property
+    def vals(self):
+        if self._vals is None:
+            self._vals = normalize(self.graph, "symmetric", "none", self.p, self.seed, self.stream_id).vals
+        return self._vals
+
+    @vals.setter
+    def vals(self, value):
+        self._vals = value
+
+    def transposed_values(self):
+        if self.vals_t is None:
+            self.vals_t = normalize(self.graph, "symmetric", "none", self.p, self.seed, self.stream_id, transposed_only=True).vals_t
+        return self.vals_t
+
+
+def dropped_adjacency(graph: DeviceGraph, p, seed, stream_id) -> Adjacency:
+    """A training iteration's adjacency: the fused form when the graph allows it (no duplicate COO entries, square),
+    else the materialised one."""
+    if graph.nnz_entries == graph.nnz and graph.n_rows == graph.n_cols and p > 0:
+        return DroppedAdjacency(graph, p, seed, stream_id)
+    return normalize(graph, "symmetric", "none", p, seed, stream_id)
+
+
 def normalize(graph: DeviceGraph, normalized="symmetric", add_eye="none", dropout=0.0, seed=0, stream_id=0,
               transposed_only=False) -> Adjacency:
     """GNN.get_adjacency on the device (reference gnn.py:36-50).  ``transposed_only``: write the values in the
@@ -185,6 +224,12 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
             raise Exception("spmm: H0 shape mismatch")
         else:
             ldh0 = H0.stride(0)
+    if isinstance(adj, DroppedAdjacency) and out_rows is None:       # weights produced inside the kernel
+        with torch.cuda.device(X.device):
+            nat.check(nat.lib().gnx_spmm_dropped(g.handle, nat.ptr(adj.D), adj.p, adj.seed, adj.stream_id, 1 if transposed else 0,
+                                                 nat.ptr(X), X.stride(0), C, nat.ptr(H0), ldh0, float(beta), float(alpha), int(act),
+                                                 nat.ptr(out), out.stride(0), nat.current_stream()))
+        return out
     if transposed:
         fn, values = nat.lib().gnx_spmm_tv, adj.transposed_values()
     else:

@@ -145,6 +145,18 @@ int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, co
                      int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha, int act,
                      const int32_t *d_out_rows, float *d_out, int64_t ldo, void *stream);
 
+/* gnx_spmm_dropped: gnx_spmm (transposed == 0) or gnx_spmm_tv (transposed != 0) over the dropped + symmetrically
+ * re-normalised adjacency of ONE training iteration WITHOUT materialising its values: every entry's weight
+ * (D[row] * dropout(raw)) * D[col] is produced inside the kernel from the counter RNG -- the same arithmetic, bit for bit, as
+ * gnx_graph_normalize(g, GNX_NORM_SYMMETRIC, GNX_EYE_NONE, dropout_p, seed, stream_id, ...) followed by gnx_spmm.
+ * d_D [n]: the degree scales of that iteration = gnx_graph_colsum(g, dropout_p, seed, stream_id, d_D) then
+ * gnx_degree_scale(d_D, n, GNX_NORM_SYMMETRIC, 0).  Saves the nnz-sized value array and the pass that writes it
+ * (layered.py:47-50 + gnn.py:41-42 happen in the SpMM's value fetch).  Square graphs; GNX_ERR_UNSUPPORTED when the COO held
+ * duplicate entries (their per-entry dropout needs the entry lists: use gnx_graph_normalize). */
+int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int transposed,
+                     const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha,
+                     int act, float *d_out, int64_t ldo, void *stream);
+
 /* gnx_spmm_rows: the fused step for a handle that holds only a SUBSET of the output rows (the interior or the
  * boundary rows of a vertex block, compacted): result row r lands in out[d_rows[r], :] and mixes in
  * H0[d_rows[r], :] (d_rows int32 [n_rows of the handle]; out and H0 are the full-height matrices).  Same

@@ -373,6 +373,38 @@ def test_transposed_order_values(gnntf):
         gnntf.spmm(a_t, G)
 
 
+@pytest.mark.parametrize("C", [3, 8, 24, 64, 100, 128, 256, 300])
+def test_dropped_adjacency_fused_into_spmm_bitwise(gnntf, C):
+    """gnx_spmm_dropped: the dropped + re-normalised values produced inside the SpMM kernels == gnx_graph_normalize followed by
+    gnx_spmm / gnx_spmm_tv, BIT FOR BIT, in every dispatch class, with hub rows (long-row kernels), forward and transposed."""
+    from gnntf.sparse import _launch, DroppedAdjacency
+    n = 2500
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 30000, seed=7)
+    hub = np.random.default_rng(1).choice(np.arange(1, n), size=1300, replace=False)            # > 2 chunks of 512
+    coo = np.unique(np.concatenate([coo, np.stack([np.zeros_like(hub), hub], 1), np.stack([hub, np.zeros_like(hub)], 1)]), axis=0)
+    vals = (np.random.default_rng(2).random(len(coo)) + 0.5).astype(np.float32)                 # weighted and NOT symmetric in value
+    g = make_graph(gnntf, coo, vals, shape)
+    assert g.nnz == g.nnz_entries
+    rng = np.random.default_rng(C)
+    X, H0 = dev(rng.standard_normal((n, C)).astype(np.float32)), dev(rng.standard_normal((n, C)).astype(np.float32))
+    fused = gnntf.sparse.dropped_adjacency(g, 0.5, 21, 6)
+    assert isinstance(fused, DroppedAdjacency)
+    two_pass = gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=21, stream_id=6)
+    for transposed in (False, True):
+        a = _launch(fused, X, H0, 0.9, 0.1, 0, transposed=transposed)
+        kernel = g.last_kernel()
+        b = _launch(two_pass, X, H0, 0.9, 0.1, 0, transposed=transposed)
+        assert torch.equal(a, b), (C, transposed, float((a - b).abs().max()))
+        assert kernel.endswith("_drop")
+    assert torch.equal(fused.vals, two_pass.vals)                       # materialised on demand for custom layers
+    ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=0.5, training=True, seed=21, stream=6, dtype=np.float64)
+    want = orc.sparse_dense_matmul(ai, av, shape, X.cpu().numpy().astype(np.float64)) * 0.9 + 0.1 * H0.cpu().numpy()
+    np.testing.assert_allclose(_launch(fused, X, H0, 0.9, 0.1, 0).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    # duplicates in the COO: per-entry dropout needs the entry lists -> the materialised form is used
+    dup = make_graph(gnntf, np.concatenate([coo, coo[:50]]), np.concatenate([vals, vals[:50]]), shape)
+    assert not isinstance(gnntf.sparse.dropped_adjacency(dup, 0.5, 1, 1), DroppedAdjacency)
+
+
 @pytest.mark.parametrize("C", [7, 64])
 def test_backward_matches_oracle(gnntf, C):
     coo, vals, shape = graphs.random_coo(400, 400, 5000, seed=31, weighted=True)
