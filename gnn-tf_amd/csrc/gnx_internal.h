@@ -118,8 +118,8 @@ struct DropFuse {
 
 __device__ __forceinline__ float dropped_weight(const DropFuse &f, float raw, int64_t r, int64_t c) {
     const int64_t ar = f.transposed ? c : r, ac = f.transposed ? r : c;      // the entry's (row, col) in A
-    const float v = hash_u24(f.seed, f.stream, (uint64_t)ar, (uint64_t)ac, 0) >= f.thr ? raw * f.scale : 0.f;
-    return (f.D[ar] * v) * f.D[ac];
+    if (hash_u24(f.seed, f.stream, (uint64_t)ar, (uint64_t)ac, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
+    return (f.D[ar] * (raw * f.scale)) * f.D[ac];
 }
 
 struct SpmmArgs {

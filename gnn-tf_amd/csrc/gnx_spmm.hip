@@ -96,6 +96,33 @@ __device__ __forceinline__ void wave_accumulate(const int32_t *__restrict__ coli
             if (FUSE) myval = dropped_weight(*fuse, myval, row, mycol);      // one entry per lane: 64 weights per wave instruction
         }
         int i = 0;
+        if (FUSE) {
+            // a dropped entry has weight exactly 0: its row is not gathered at all (fmaf(0, x, acc) == acc for finite x), so a
+            // training iteration moves only the kept rows -- half of them at p = 0.5; kept entries stay in ascending order
+            uint64_t keep = __ballot(myval != 0.f);
+            while (keep) {
+                float x[U][VEC];
+                int idx[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    idx[u] = keep ? (int)__builtin_ctzll(keep) : -1;
+                    if (keep) keep &= keep - 1;
+                    if (idx[u] >= 0) {
+                        const int j = readlane_i(mycol, idx[u]);
+                        vload<VEC>(x[u], X + (int64_t)j * ldx + c);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (idx[u] >= 0) {
+                        const float w = readlane_f(myval, idx[u]);
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w, x[u][v], acc[v]);
+                    }
+                }
+            }
+            continue;
+        }
         for (; i + U <= n; i += U) {
             float x[U][VEC];
 #pragma unroll
@@ -506,15 +533,21 @@ __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
                 mycol = p.colidx[base + sub];
                 myw = dropped_weight(p.fuse, p.vals[base + sub], row, mycol);
             }
-            for (int i = 0; i < n; i += U) {
+            // dropped entries (weight exactly 0) are not gathered: the group walks only the kept entries of its round, in order
+            const uint64_t all = __ballot(myw != 0.f);
+            uint32_t keep = (uint32_t)(all >> ((threadIdx.x & 63) / G * G)) & (G == 32 ? 0xFFFFFFFFu : ((1u << G) - 1u));
+            while (keep) {
                 float x[U][VEC];
                 float w[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int j = __shfl(mycol, i + u, G);
-                    w[u] = __shfl(myw, i + u, G);
-                    if (i + u < n) vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
-                    else {
+                    if (keep) {
+                        const int idx = __builtin_ctz(keep);
+                        keep &= keep - 1;
+                        const int j = __shfl(mycol, idx, G);
+                        w[u] = __shfl(myw, idx, G);
+                        vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                    } else {
                         w[u] = 0.f;
 #pragma unroll
                         for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
@@ -585,6 +618,7 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_group_drop(const Spmm
             mycol = p.colidx[base + lane];
             myw = dropped_weight(p.fuse, p.vals[base + lane], row, mycol);
         }
+#pragma unroll 1
         for (int k = 0; k < G; k += U) {
             float x[U][VEC];
             float w[U];
@@ -593,7 +627,7 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_group_drop(const Spmm
                 const int src = sub + (k + u) * NS;                  // entry of the round this sub-group takes in slot k + u
                 const int j = __shfl(mycol, src);
                 w[u] = __shfl(myw, src);
-                if (k + u < G && src < n) vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                if (k + u < G && src < n && w[u] != 0.f) vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);   // dropped: not gathered
                 else {
                     w[u] = 0.f;
 #pragma unroll
