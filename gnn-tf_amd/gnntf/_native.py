@@ -47,6 +47,11 @@ SIGNATURES = {
     "gnx_ppr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
     "gnx_appnp_propagate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p]),
+    "gnx_halo_plan_create": (c_int, [c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "gnx_halo_plan_destroy": (c_int, [c_void_p]),
+    "gnx_halo_plan_layout": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p]),
+    "gnx_halo_pack": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gnx_halo_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gnx_gcnii_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_int64, c_int, c_void_p,
                                c_void_p, c_void_p]),

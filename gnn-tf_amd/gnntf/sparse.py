@@ -62,6 +62,12 @@ class DeviceGraph:
         if csr is not None:
             rowptr, colidx, vals, shape = csr
             nat.require_cuda(rowptr, colidx, vals)
+            if (rowptr.dtype, colidx.dtype, vals.dtype) != (torch.int64, torch.int32, torch.float32):
+                raise Exception("DeviceGraph: a CSR needs int64 rowptr, int32 colidx and float32 values")
+            if not (rowptr.device == colidx.device == vals.device):
+                raise Exception("DeviceGraph: the CSR arrays live on different devices")
+            if rowptr.numel() != shape[0] + 1 or colidx.numel() != vals.numel():
+                raise Exception("DeviceGraph: CSR array lengths do not match the shape")
             self.device = rowptr.device
             self._keep = (rowptr.contiguous(), colidx.contiguous(), vals.contiguous())
             with torch.cuda.device(self.device):
@@ -76,6 +82,7 @@ class DeviceGraph:
             self.device = device
             idx = coo.indices.to(device).contiguous()
             val = coo.values.to(device).contiguous()
+            self.device = idx.device                        # with its index ("cuda" -> "cuda:0")
             with torch.cuda.device(device):
                 nat.check(lib.gnx_graph_create_coo(coo.dense_shape[0], coo.dense_shape[1], idx.shape[0], nat.ptr(idx),
                                                    nat.ptr(val), nat.current_stream(), byref(self._h)))
@@ -202,9 +209,17 @@ def _as_f32_rows(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _same_device(g, *tensors):
+    """Raw pointers cross the C ABI: every operand must live on the graph's device."""
+    for t in tensors:
+        if t is not None and t.device != g.device:
+            raise Exception(f"spmm: operand on {t.device}, the graph lives on {g.device}")
+
+
 def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None, out_rows=None):
     g = adj.graph
     nat.require_cuda(X, H0)
+    _same_device(g, X, H0, out, out_rows, adj.diag)
     X = _as_f32_rows(X)
     rows_in = g.n_rows if transposed else g.n_cols
     rows_out = g.n_cols if transposed else g.n_rows
@@ -255,6 +270,7 @@ def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out):
     a vertex block): result row r is written to out[rows[r]] and mixes in H0[rows[r]] (gnx_spmm_rows)."""
     g = adj.graph
     nat.require_cuda(X, H0, rows, out)
+    _same_device(g, X, H0, rows, out)
     X = _as_f32_rows(X)
     if X.shape[0] != g.n_cols:
         raise Exception(f"spmm: features have {X.shape[0]} rows, adjacency expects {g.n_cols}")

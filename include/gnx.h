@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 typedef struct gnx_graph *gnx_graph_t;
+typedef struct gnx_halo_plan *gnx_halo_plan_t;
 
 enum { GNX_OK = 0, GNX_ERR_INVALID = -1, GNX_ERR_HIP = -2, GNX_ERR_ALLOC = -3, GNX_ERR_UNSUPPORTED = -4 };
 
@@ -206,6 +207,30 @@ int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t C, const in
                          int64_t m, const float *d_grad_loss, float *d_grad_logits, int64_t ldg, void *stream);
 int gnx_node_argmax(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, int64_t m,
                     int64_t *d_out, void *stream);
+
+/* ---- vertex-partitioned propagation (multi-GPU; the reference has no counterpart -- SURVEY.md section 8(e)) ----------------
+ * One process per GPU owns a contiguous block of rows.  Its feature buffer is
+ *     X = [ region(0) .. region(self-1) | n_local local rows | region(self+1) .. region(n_ranks-1) ],
+ * region(q) = the recv_rows[q] rows rank q sends per iteration: rows of H pulled from q and/or partial sums
+ * sum_j A_hat[i, j] H[j] pushed by q for rows i of this block (the caller's plan decides which; gnntf/sharded.py chooses a
+ * vertex cover of the cross entries).  The main CSR of the block indexes X directly (gnx_graph_create_coo / _csr over
+ * n_buf columns; pushed partial sums appear as weight-1 entries); the SEND graph [sum(send_rows) x n_local] produces every
+ * outgoing row as a sparse combination of local rows (a pulled row = one entry of weight 1), in peer order.
+ *   gnx_halo_plan_create   counts per peer (rows; [self] must be 0) + the send graph (borrowed; may be NULL when nothing is sent)
+ *   gnx_halo_plan_layout   n_buf, first local row, rows to send, first row of every peer's region in X / in the send buffer
+ *   gnx_halo_pack          d_send[n_send, C] = send_graph . X[local rows]          (one SpMM launch; stream-ordered)
+ *   gnx_halo_exchange      RCCL group of ncclRecv into the regions of d_X + ncclSend of the slices of d_send; d_X and d_send
+ *                          contiguous with row length C; `nccl_comm` is the caller's ncclComm_t whose ranks are the plan's
+ *                          ranks.  Returns GNX_ERR_UNSUPPORTED when RCCL's symbols are not loaded in the process: move the
+ *                          rows yourself (any transport) using the offsets of gnx_halo_plan_layout.
+ * One iteration = gnx_halo_pack -> exchange -> gnx_spmm (or gnx_spmm_rows) over X into the local rows of the other buffer. */
+int gnx_halo_plan_create(int n_ranks, int self, int64_t n_local, const int64_t *recv_rows, const int64_t *send_rows,
+                         gnx_graph_t send_graph, gnx_halo_plan_t *out);
+int gnx_halo_plan_destroy(gnx_halo_plan_t plan);
+int gnx_halo_plan_layout(gnx_halo_plan_t plan, int64_t *n_buf, int64_t *local_row0, int64_t *n_send, int64_t *recv_row0,
+                         int64_t *send_row0);
+int gnx_halo_pack(gnx_halo_plan_t plan, const float *d_X, int64_t ldx, int64_t C, float *d_send, int64_t lds, void *stream);
+int gnx_halo_exchange(gnx_halo_plan_t plan, void *nccl_comm, const float *d_send, float *d_X, int64_t C, void *stream);
 
 /* Halo packing for the vertex-partitioned path: out[r,:] = X[idx[r],:], idx int64 [n_idx]. */
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,
