@@ -49,16 +49,10 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < p.F; k0 += Cfg::KC) {
-        __syncthreads();                                                   // the previous chunk has been consumed
-        for (int idx = threadIdx.x; idx < Cfg::KC * Cfg::OP; idx += 256) {
-            const int r = idx / Cfg::OP, cc = idx % Cfg::OP;
-            const int k = k0 + r;
-            Ws[r * Cfg::STRIDE + cc] = (k < p.F && cc < p.O) ? p.W[(int64_t)k * p.ldw + cc] : 0.f;
-        }
-        float a[Cfg::KC / 16][4];
+    // A values of one K chunk: 16 bytes per lane and 16-wide step, straight from HBM into the MFMA operand registers
+    auto load_a = [&](int k0, float (&a)[Cfg::KC / 16][4]) {
 #pragma unroll
-        for (int T = 0; T < Cfg::KC / 16; ++T) {                           // every A value of the chunk in flight before the first MFMA
+        for (int T = 0; T < Cfg::KC / 16; ++T) {
             const int kb = k0 + 16 * T + 4 * g;
             if (ALIGNED && kb + 3 < p.F) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow + kb);
@@ -68,6 +62,17 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
                 for (int t = 0; t < 4; ++t) a[T][t] = kb + t < p.F ? xrow[kb + t] : 0.f;
             }
         }
+    };
+    float a[Cfg::KC / 16][4], a_next[Cfg::KC / 16][4];
+    load_a(0, a);
+    for (int k0 = 0; k0 < p.F; k0 += Cfg::KC) {
+        __syncthreads();                                                   // the previous chunk has been consumed
+        for (int idx = threadIdx.x; idx < Cfg::KC * Cfg::OP; idx += 256) {
+            const int r = idx / Cfg::OP, cc = idx % Cfg::OP;
+            const int k = k0 + r;
+            Ws[r * Cfg::STRIDE + cc] = (k < p.F && cc < p.O) ? p.W[(int64_t)k * p.ldw + cc] : 0.f;
+        }
+        if (k0 + Cfg::KC < p.F) load_a(k0 + Cfg::KC, a_next);              // the next chunk's rows are in flight under this chunk's MFMAs
         __syncthreads();
 #pragma unroll
         for (int T = 0; T < Cfg::KC / 16; ++T) {
@@ -79,6 +84,10 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[T][t], wrow[16 * nt], acc[nt], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int T = 0; T < Cfg::KC / 16; ++T)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[T][t] = a_next[T][t];
     }
     // D layout: lane (c, g), register r -> row 4g + r, column 16 nt + c
 #pragma unroll
@@ -163,11 +172,28 @@ __global__ __launch_bounds__(256) void k_node_ce_bwd(const float *__restrict__ l
     }
 }
 
-// mean of m values in a fixed order (one block; a fixed LDS tree over 256 strided partial sums)
-__global__ __launch_bounds__(256) void k_mean(const float *__restrict__ v, int64_t m, float *__restrict__ out) {
+// mean of m values in a fixed order: MEAN_BLOCKS blocks each reduce a contiguous slice (strided partial sums + a fixed LDS
+// tree) into partial[block]; one block then adds the partials in the same way and divides
+constexpr int MEAN_BLOCKS = 256;
+__global__ __launch_bounds__(256) void k_mean_partial(const float *__restrict__ v, int64_t m, float *__restrict__ partial) {
+    __shared__ float red[256];
+    const int64_t per = (m + MEAN_BLOCKS - 1) / MEAN_BLOCKS;
+    const int64_t b = (int64_t)blockIdx.x * per, e = b + per < m ? b + per : m;
+    float acc = 0.f;
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) acc += v[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void k_mean(const float *__restrict__ v, int64_t n_partial, int64_t m, float *__restrict__ out) {
     __shared__ float red[256];
     float acc = 0.f;
-    for (int64_t i = threadIdx.x; i < m; i += 256) acc += v[i];
+    for (int64_t i = threadIdx.x; i < n_partial; i += 256) acc += v[i];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -261,7 +287,16 @@ int gnx_node_ce(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, c
     GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_node_ce_fwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_logits, ldl, (int)C, n_rows, d_nodes, d_labels, m,
                        d_loss_per_node, bad);
-    hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, s, d_loss_per_node, m, d_mean_loss);
+    if (m > 4096) {
+        float *partial = nullptr;
+        GNX_HIP(hipMalloc((void **)&partial, MEAN_BLOCKS * sizeof(float)));
+        hipLaunchKernelGGL(k_mean_partial, dim3(MEAN_BLOCKS), dim3(256), 0, s, d_loss_per_node, m, partial);
+        hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, s, partial, (int64_t)MEAN_BLOCKS, m, d_mean_loss);
+        GNX_HIP(hipStreamSynchronize(s));
+        (void)hipFree(partial);
+    } else {
+        hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, s, d_loss_per_node, m, m, d_mean_loss);
+    }
     int h_bad = 0;
     GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
     GNX_HIP(hipStreamSynchronize(s));
