@@ -148,6 +148,7 @@ struct SpmmArgs {
     float *partial;
     int64_t n_long, n_chunks;
     int tune;
+    bool skip_empty;           // GNX_ACT_SKIP_EMPTY: rows without entries are left untouched
     DropFuse fuse;
 };
 

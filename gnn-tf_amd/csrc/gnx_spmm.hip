@@ -202,6 +202,7 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
     const int64_t row = (p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > LONG_ROW) return;  // k_spmm_long_* take it
+    if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY: the row already holds alpha * H0 from an earlier iteration
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
         const int c = c0 + lane * VEC;
         const bool active = c < p.C;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;   // degree-binned: the rows of one wave have similar lengths
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > LONG_ROW) return;
+    if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
         const int c = c0 + sub * VEC;
         const bool active = c < p.C;
@@ -796,6 +798,8 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
 #endif
     p.n_long = m.n_long; p.n_chunks = m.n_chunks;
     p.partial = nullptr;
+    p.skip_empty = (p.act & GNX_ACT_SKIP_EMPTY) != 0 && p.diag == nullptr;
+    p.act &= ~GNX_ACT_SKIP_EMPTY;
     if (m.n_rows == 0) return GNX_OK;
     if (m.n_long > 0) {
         int rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)p.C * sizeof(float));
@@ -833,7 +837,7 @@ int gnx_spmm(gnx_graph_t g, const float *d_vals, const float *d_diag, const floa
              const float *d_H0, int64_t ldh0, float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream) {
     int rc = check_common("gnx_spmm", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
     if (rc != GNX_OK) return rc;
-    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm: invalid activation %d", act);
+    GNX_CHECK_ARG((act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_NONE || (act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_RELU, "gnx_spmm: invalid activation %d", act);
     GNX_CHECK_ARG(d_diag == nullptr || g->a.n_rows == g->a.n_cols, "gnx_spmm: diag needs a square graph");
     SpmmArgs p{};
     p.vals = d_vals ? d_vals : g->raw_vals;
@@ -879,7 +883,7 @@ int gnx_spmm_rows(gnx_graph_t g, const float *d_vals, const float *d_X, int64_t 
                   float beta, float alpha, int act, const int32_t *d_rows, float *d_out, int64_t ldo, void *stream) {
     int rc = check_common("gnx_spmm_rows", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
     if (rc != GNX_OK) return rc;
-    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_rows: invalid activation %d", act);
+    GNX_CHECK_ARG((act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_NONE || (act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_RELU, "gnx_spmm_rows: invalid activation %d", act);
     GNX_CHECK_ARG(d_rows != nullptr || g->a.n_rows == 0, "gnx_spmm_rows: NULL row map");
     SpmmArgs p{};
     p.vals = d_vals ? d_vals : g->raw_vals;
@@ -1007,10 +1011,15 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
         GNX_HIP(hipMemcpyAsync(d_out, d_H0, (size_t)g->a.n_rows * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return GNX_OK;
     }
+    // A row without entries is a * H0 after every iteration and nobody's sum depends on when it was written: such rows are
+    // computed the first time each of the two buffers is a destination (k = 0, 1) and left alone afterwards (GNX_ACT_SKIP_EMPTY)
+    // -- on the R-MAT workloads 60 % of the rows, 7-10 % of an iteration's bytes.  Same arithmetic, same bits.
     const float *src = d_H0;
     for (int k = 0; k < K; ++k) {
         float *dst = ((K - 1 - k) % 2 == 0) ? d_out : d_work;
-        int rc = gnx_ppr_step(g, d_vals, d_diag, src, d_H0, a, C, GNX_ACT_NONE, dst, stream);
+        const int act = (k >= 2 && d_diag == nullptr) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
+        GNX_CHECK_ARG(d_H0 != nullptr, "gnx_appnp_propagate: NULL H0");
+        int rc = gnx_spmm(g, d_vals, d_diag, src, C, C, d_H0, C, (float)(1.0 - (double)a), a, act, dst, C, stream);
         if (rc != GNX_OK) return rc;
         src = dst;
     }

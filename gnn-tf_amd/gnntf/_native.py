@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
 
 NORM = {"none": 0, "symmetric": 1, "bipartite": 2}
 EYE = {"none": 0, "before": 1, "after": 2}
-ACT_NONE, ACT_RELU = 0, 1
+ACT_NONE, ACT_RELU, ACT_SKIP_EMPTY = 0, 1, 256
 
 # name -> (restype, argtypes); must list every symbol include/gnx.h declares
 SIGNATURES = {

@@ -79,14 +79,16 @@ class NativeBackend:
                                                        nat.ptr(out), nat.current_stream()))
         return out
 
-    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out, out_rows=None, rows=None):
+    def spmm_mix(self, graph, vals, X, H0, beta, alpha, out, out_rows=None, rows=None, skip_empty=False):
         """out[i] = beta * (A X)[i] + alpha * H0[i];  ``rows``: the graph holds a subset of the output rows --
-        result row r belongs to out[rows[r]] / H0[rows[r]];  ``out_rows``: scatter of the result only."""
+        result row r belongs to out[rows[r]] / H0[rows[r]];  ``out_rows``: scatter of the result only;
+        ``skip_empty``: rows without entries already hold alpha * H0 and are left alone (GNX_ACT_SKIP_EMPTY)."""
         adj = sparse.Adjacency(graph, vals)
+        act = nat.ACT_NONE | (nat.ACT_SKIP_EMPTY if skip_empty else 0)
         if rows is not None:
-            sparse.launch_rows(adj, X, H0, beta, alpha, rows, out)
+            sparse.launch_rows(adj, X, H0, beta, alpha, rows, out, act=act)
         else:
-            sparse._launch(adj, X, H0, beta, alpha, nat.ACT_NONE, out=out, out_rows=out_rows)
+            sparse._launch(adj, X, H0, beta, alpha, act, out=out, out_rows=out_rows)
 
     def spmm_plain(self, graph, X, out):
         sparse._launch(sparse.Adjacency(graph, None), X, None, 1.0, 0.0, nat.ACT_NONE, out=out)
@@ -550,16 +552,16 @@ class ShardedGraph:
         recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
         self.comm.exchange(sends, recvs)
 
-    def _compute(self, state, c, src, out, a, interior):
+    def _compute(self, state, c, src, out, a, interior, skip_empty=False):
         c0, c1 = state.cols[c]
         H0 = state.H0[:, c0:c1]
         if not self.split_rows:
             if not interior:
-                self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out)
+                self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out, skip_empty=skip_empty)
         elif interior:
-            self.backend.spmm_mix(self.graph_int, None, src, H0, 1.0 - a, a, out, rows=self.rows_int)
+            self.backend.spmm_mix(self.graph_int, None, src, H0, 1.0 - a, a, out, rows=self.rows_int, skip_empty=skip_empty)
         else:
-            self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out, rows=self.rows_bnd)
+            self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out, rows=self.rows_bnd, skip_empty=skip_empty)
 
     def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10):
         """H <- H0, then K iterations; returns this rank's rows of the result (in the caller's vertex order)."""
@@ -576,6 +578,9 @@ class ShardedGraph:
             packed.append(lanes.mark())
         for k in range(iterations):
             last = k == iterations - 1
+            # a row without entries is a * H0 after every iteration: it is written the first time each ping-pong buffer is a
+            # destination (k = 0, 1) and into the result (last iteration), and left alone in between
+            settled = 2 <= k < iterations - 1
             for c, (c0, c1) in enumerate(state.cols):
                 src, dst = state.bufs[c][k % 2], state.bufs[c][1 - k % 2]
                 with lanes.exchange_lane():                            # runs under the other chunk's SpMM
@@ -583,9 +588,9 @@ class ShardedGraph:
                     self._exchange(state, c, src)
                     arrived = lanes.mark(on_exchange_lane=True)
                 out = state.result[:, c0:c1] if last else self.local_view(dst)
-                self._compute(state, c, src, out, a, interior=True)    # needs no halo
+                self._compute(state, c, src, out, a, interior=True, skip_empty=settled)    # needs no halo
                 lanes.wait(arrived)
-                self._compute(state, c, src, out, a, interior=False)
+                self._compute(state, c, src, out, a, interior=False, skip_empty=settled)
                 if not last:
                     self._pack(state, c, dst)
                     packed[c] = lanes.mark()
@@ -638,8 +643,8 @@ class ShardedGraph:
             else:
                 for c in range(len(state.cols)):
                     src, dst = state.bufs[c][0], state.bufs[c][1]
-                    self._compute(state, c, src, self.local_view(dst), a, interior=True)
-                    self._compute(state, c, src, self.local_view(dst), a, interior=False)
+                    self._compute(state, c, src, self.local_view(dst), a, interior=True, skip_empty=True)    # a steady-state iteration
+                    self._compute(state, c, src, self.local_view(dst), a, interior=False, skip_empty=True)
                     self._pack(state, c, dst)
             self._sync()
             dt = time.perf_counter() - t0

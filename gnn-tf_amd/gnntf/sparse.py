@@ -265,7 +265,7 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
     return out
 
 
-def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out):
+def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out, act=nat.ACT_NONE):
     """The fused step over a graph that holds a SUBSET of the output rows (the interior or the boundary rows of
     a vertex block): result row r is written to out[rows[r]] and mixes in H0[rows[r]] (gnx_spmm_rows)."""
     g = adj.graph
@@ -287,7 +287,7 @@ def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out):
         ldh0 = H0.stride(0)
     with torch.cuda.device(X.device):
         nat.check(nat.lib().gnx_spmm_rows(g.handle, nat.ptr(adj.vals), nat.ptr(X), X.stride(0), C, nat.ptr(H0), ldh0, float(beta),
-                                          float(alpha), nat.ACT_NONE, nat.ptr(rows), nat.ptr(out), out.stride(0),
+                                          float(alpha), int(act), nat.ptr(rows), nat.ptr(out), out.stride(0),
                                           nat.current_stream()))
     return out
 

@@ -39,6 +39,10 @@ enum { GNX_NORM_NONE = 0, GNX_NORM_SYMMETRIC = 1, GNX_NORM_BIPARTITE = 2 };
 enum { GNX_EYE_NONE = 0, GNX_EYE_BEFORE = 1, GNX_EYE_AFTER = 2 };
 /* epilogue activation: identity (filter.py:8 default) or relu (gcn.py:78 default) */
 enum { GNX_ACT_NONE = 0, GNX_ACT_RELU = 1 };
+/* flag OR'ed into `act` of gnx_spmm / gnx_spmm_rows: rows without stored entries are NOT written (their output would be
+ * alpha * H0[row], which is what an earlier iteration of a propagation loop already left there) -- they cost one rowptr read
+ * instead of a row of H0 and a row of out.  Ignored when a diagonal weight is given. */
+enum { GNX_ACT_SKIP_EMPTY = 256 };
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *gnx_last_error(void);

@@ -59,11 +59,16 @@ class OracleBackend:
         m = sp.csr_matrix((g.vals if vals is None else vals.numpy(), g.colidx, g.rowptr), shape=g.shape)
         return m @ X.numpy()
 
-    def spmm_mix(self, g, vals, X, H0, beta, alpha, out, out_rows=None, rows=None):
+    def spmm_mix(self, g, vals, X, H0, beta, alpha, out, out_rows=None, rows=None, skip_empty=False):
         prod = self._product(g, vals, X) * np.float32(beta)
+        keep = torch.from_numpy(np.diff(g.rowptr) > 0) if skip_empty else torch.ones(g.n_rows, dtype=torch.bool)
         if rows is not None:
-            r = rows.long()
-            out[r] = torch.from_numpy(prod) + H0[r] * np.float32(alpha)
+            r = rows.long()[keep]
+            out[r] = torch.from_numpy(prod)[keep] + H0[r] * np.float32(alpha)
+            return
+        if skip_empty:
+            assert out_rows is None
+            out[keep] = torch.from_numpy(prod)[keep] + H0[keep] * np.float32(alpha)
             return
         res = torch.from_numpy(prod + H0.numpy() * np.float32(alpha))
         if out_rows is None:

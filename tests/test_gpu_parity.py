@@ -175,6 +175,35 @@ def test_nan_semantics_match(gnntf):
     assert got[-1] == 0 and want[-1] == 0                                 # divide_no_nan(1, 0) = 0 on the zero column
 
 
+def test_k_loop_skips_settled_empty_rows_bitwise(gnntf):
+    """gnx_appnp_propagate leaves rows without entries alone once both ping-pong buffers hold their a * H0 (GNX_ACT_SKIP_EMPTY):
+    the result must equal, bit for bit, K separate full steps -- also when an EMPTY row's column is read by other rows
+    (directed pattern) and for every parity of K."""
+    rng = np.random.default_rng(12)
+    n = 4000
+    rows = rng.integers(0, n // 2, size=30000)                  # rows n/2 .. n-1 have no entries ...
+    cols = rng.integers(0, n, size=30000)                       # ... but their columns are referenced
+    coo = np.unique(np.stack([rows, cols], 1), axis=0)
+    vals = (rng.random(len(coo)) + 0.5).astype(np.float32)
+    g = make_graph(gnntf, coo, vals, (n, n))
+    adj = gnntf.normalize(g, "none")
+    for C in (8, 64, 256):
+        H0 = dev(rng.standard_normal((n, C)).astype(np.float32))
+        for K in (1, 2, 3, 6, 7):
+            H = H0
+            for _ in range(K):
+                H = gnntf.ppr_step(adj, H, H0, 0.2)
+            got = gnntf.appnp_propagate(adj, H0, a=0.2, iterations=K)
+            assert torch.equal(got, H), (C, K)
+            assert torch.equal(got[n // 2:], H0[n // 2:] * 0.2)
+    eye = gnntf.normalize(g, "none", "after")                   # a diagonal term makes empty rows depend on the iterate: nothing is skipped
+    H0 = dev(rng.standard_normal((n, 16)).astype(np.float32))
+    H = H0
+    for _ in range(5):
+        H = gnntf.ppr_step(eye, H, H0, 0.2)
+    assert torch.equal(gnntf.appnp_propagate(eye, H0, a=0.2, iterations=5), H)
+
+
 def test_hand_graphs(gnntf):
     """KAT-2 on the device: isolated nodes -> a*H0; doubled COO == single COO; directed column-sum rule."""
     idx, vals, shape = orc.graph2adj(range(8), [(0, i) for i in range(1, 6)])
