@@ -230,6 +230,41 @@ __global__ __launch_bounds__(256) void k_node_argmax(const float *__restrict__ l
     if (sub == 0) out[i] = arg < C ? arg : 0;
 }
 
+// ---- link head: logit_i = sum_c F[u_i, c] * F[v_i, c] * (r[c] or 1)   (graph_predictor.py:122-126) ---------------------
+__global__ __launch_bounds__(256) void k_edge_scores(const float *__restrict__ F, int64_t ldf, int C, int64_t n_rows,
+                                                      const int64_t *__restrict__ edges, int64_t m, const float *__restrict__ r,
+                                                      float *__restrict__ out, int *__restrict__ bad) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= m) return;
+    const int64_t u = edges[2 * i], v = edges[2 * i + 1];
+    if (u < 0 || u >= n_rows || v < 0 || v >= n_rows) {
+        if (sub == 0) { atomicExch(bad, 1); out[i] = 0.f; }
+        return;
+    }
+    const float *__restrict__ fu = F + u * ldf, *__restrict__ fv = F + v * ldf;
+    float acc = 0.f;
+    for (int c = sub; c < C; c += 16) acc = fmaf(fu[c] * fv[c], r ? r[c] : 1.0f, acc);
+    acc = group16_sum(acc);
+    if (sub == 0) out[i] = acc;
+}
+
+// dF[u_i, :] += g_i * F[v_i, :] * r,  dF[v_i, :] += g_i * F[u_i, :] * r   (atomics: endpoints repeat across edges)
+__global__ __launch_bounds__(256) void k_edge_scores_bwd(const float *__restrict__ F, int64_t ldf, int C, const int64_t *__restrict__ edges,
+                                                          int64_t m, const float *__restrict__ r, const float *__restrict__ g,
+                                                          float *__restrict__ dF, int64_t ldg) {
+    const int sub = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= m) return;
+    const int64_t u = edges[2 * i], v = edges[2 * i + 1];
+    const float gi = g[i];
+    for (int c = sub; c < C; c += 16) {
+        const float w = gi * (r ? r[c] : 1.0f);
+        atomicAdd(dF + u * ldg + c, w * F[v * ldf + c]);
+        atomicAdd(dF + v * ldg + c, w * F[u * ldf + c]);
+    }
+}
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
 
 }  // namespace
@@ -310,6 +345,35 @@ int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t C, const in
     GNX_CHECK_ARG(d_logits && d_nodes && d_labels && d_grad_loss && d_grad_logits, "gnx_node_ce_backward: NULL pointer");
     hipLaunchKernelGGL(k_node_ce_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_logits, ldl, (int)C, d_nodes,
                        d_labels, m, d_grad_loss, 1.0f / (float)m, d_grad_logits, ldg);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_edge_scores(const float *d_F, int64_t ldf, int64_t n_rows, int64_t C, const int64_t *d_edges, int64_t m, const float *d_r,
+                    float *d_out, void *stream) {
+    GNX_CHECK_ARG(m >= 0 && C >= 1 && n_rows >= 0 && ldf >= C, "gnx_edge_scores: bad sizes");
+    if (m == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_F && d_edges && d_out, "gnx_edge_scores: NULL pointer");
+    hipStream_t s = (hipStream_t)stream;
+    int *bad = nullptr;
+    GNX_HIP(hipMalloc((void **)&bad, sizeof(int)));
+    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{bad};
+    GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_edge_scores, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_F, ldf, (int)C, n_rows, d_edges, m, d_r, d_out, bad);
+    int h_bad = 0;
+    GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
+    GNX_HIP(hipStreamSynchronize(s));
+    GNX_CHECK_ARG(h_bad == 0, "gnx_edge_scores: an edge endpoint is out of range");
+    return GNX_OK;
+}
+
+int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t C, const int64_t *d_edges, int64_t m, const float *d_r,
+                             const float *d_grad_out, float *d_grad_F, int64_t ldg, void *stream) {
+    GNX_CHECK_ARG(m >= 0 && C >= 1 && ldf >= C && ldg >= C, "gnx_edge_scores_backward: bad sizes");
+    if (m == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_F && d_edges && d_grad_out && d_grad_F, "gnx_edge_scores_backward: NULL pointer");
+    hipLaunchKernelGGL(k_edge_scores_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_F, ldf, (int)C, d_edges, m,
+                       d_r, d_grad_out, d_grad_F, ldg);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }

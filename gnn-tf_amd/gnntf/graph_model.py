@@ -14,10 +14,28 @@ import math
 import torch
 
 from . import sparse
-from .blocks import Dense, Dropout, affine, linear, relu
+from .blocks import Concatenate, Dense, Dropout, affine, linear, relu
 from .params import default_device
 from .protocol import Layer
 from .training import Trainable
+
+
+class Structural(Layer):
+    """gnn.py:5-26: trainable per-node embeddings (``bipartite`` rows in one variable, the rest in another), optionally
+    l2-normalised, prepended to the incoming features; with zero-width features the embeddings ARE the features."""
+
+    def __build__(self, architecture, dims: int = 16, l2_contraint: bool = False, bipartite: int = 0, **kwargs):
+        rows, width = architecture.top_shape()
+        self.l2_contraint = l2_contraint
+        self.embeddings = architecture.create_var((bipartite, dims), **kwargs)
+        self.embeddings2 = architecture.create_var((rows - bipartite, dims), **kwargs)
+        return rows, dims + width
+
+    def __forward__(self, architecture, features):
+        table = self.embeddings2 if self.embeddings.shape[0] == 0 else torch.cat([self.embeddings, self.embeddings2], dim=0)
+        if self.l2_contraint:
+            table = torch.nn.functional.normalize(table, dim=1, eps=1e-12)
+        return table if features.shape[1] == 0 else torch.cat([table, features], dim=1)
 
 
 class GNN(Trainable):
@@ -237,6 +255,46 @@ class GCNII(GNN):
             self.add(layer_type(H0, a, l, iteration, activation=relu, dropout=dropout, graph_dropout=0,
                                 regularization=convolution_regularization))
         self.add(Dense(num_classes, dropout=0, regularize=False))
+
+
+def leaky_relu(x):
+    return torch.nn.functional.leaky_relu(x, 0.2)          # tf.nn.leaky_relu's default slope
+
+
+class NGCFLayer(Layer):
+    """gcn.py:116-135: with A = the BIPARTITE-normalised adjacency (rows scaled by 1 / column sum, gnn.py:43-45),
+    l2_normalize(dropout(act((X * (A.X)).W1 + b1) + act((A.X).W2 + b2))).  The adjacency is taken ONCE, at build time
+    (gcn.py:127) -- so a ``node_dropout`` is one fixed mask, drawn while the fresh architecture is still in training mode."""
+
+    def __build__(self, gcn, outputs: int, activation=leaky_relu, bias: bool = True, dropout: float = 0, node_dropout: float = 0,
+                  regularize: float = 1):
+        rows, width = gcn.top_shape()
+        spread = 1. / rows ** 0.5
+        self.W1 = gcn.create_var((width, outputs), regularize=regularize, normalization=spread)
+        self.W2 = gcn.create_var((width, outputs), regularize=regularize, normalization=spread)
+        self.b1 = gcn.create_var((1, outputs), normalization=spread) if bias else 0
+        self.b2 = gcn.create_var((1, outputs), normalization=spread) if bias else 0
+        self.activation, self.dropout, self.node_dropout = activation, dropout, node_dropout
+        self.adjacency = gcn.get_adjacency(self.node_dropout, add_eye="none", normalized="bipartite")
+        return rows, outputs
+
+    def __forward__(self, gcn, features):
+        aggregated = sparse.spmm(self.adjacency, features)                       # the propagation kernel
+        interaction = self.activation(affine(features * aggregated, self.W1, self.b1))
+        message = self.activation(affine(aggregated, self.W2, self.b2))
+        return torch.nn.functional.normalize(gcn.dropout(interaction + message, self.dropout), dim=1, eps=1e-12)
+
+
+class NGCF(GNN):
+    """gcn.py:138-154 -- https://dl.acm.org/doi/pdf/10.1145/3468264.3468552.  The closing Concatenate stacks the layers'
+    outputs along axis 0 exactly like the reference's (layers.py:98-101), so rows 0..N-1 of the output are the FIRST layer's
+    embeddings -- which is what the link tasks index."""
+
+    def __init__(self, graph, features, num_classes: int, latent_dims=None, dropout=0.1, **kwargs):
+        super().__init__(graph, features, **kwargs)
+        widths = [num_classes] * 2 if latent_dims is None else list(latent_dims)
+        stack = [self.add(NGCFLayer(width, regularize=0.0, dropout=dropout, output_regularize=1)) for width in widths + [num_classes]]
+        self.add(Concatenate(stack))
 
 
 class MLP(Trainable):

@@ -594,3 +594,42 @@ class _SparseDense(torch.autograd.Function):
 def sparse_dense(rows: SparseRows, W: torch.Tensor, bias=None, relu=False) -> torch.Tensor:
     """act(X . W + bias) for sparse X (``bias`` [1, O] or None)."""
     return _SparseDense.apply(W, bias, rows.adjacency(), bool(relu))
+
+
+# ---- link head: the logit of every listed edge in one launch -------------------------------------------------------------
+class _EdgeScores(torch.autograd.Function):
+    """logit_i = sum_c F[u_i, c] F[v_i, c] (r[c] or 1)  (graph_predictor.py:122-126); backward scatters into dF with atomics;
+    the DistMult weights' gradient (C numbers) is a reduction over the edges, done with torch on the gathered rows."""
+
+    @staticmethod
+    def forward(ctx, F, edges, r):
+        F = _as_f32_rows(F)
+        rr = None if r is None else r.to(torch.float32).reshape(-1).contiguous()
+        out = torch.empty(edges.shape[0], dtype=torch.float32, device=F.device)
+        with torch.cuda.device(F.device):
+            nat.check(nat.lib().gnx_edge_scores(nat.ptr(F), F.stride(0), F.shape[0], F.shape[1], nat.ptr(edges), edges.shape[0], nat.ptr(rr),
+                                                nat.ptr(out), nat.current_stream()))
+        ctx.save_for_backward(F, edges, rr)
+        ctx.r_shape = None if r is None else tuple(r.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        F, edges, rr = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous()
+        gF = gr = None
+        if ctx.needs_input_grad[0]:
+            gF = torch.zeros((F.shape[0], F.shape[1]), dtype=torch.float32, device=F.device)
+            with torch.cuda.device(F.device):
+                nat.check(nat.lib().gnx_edge_scores_backward(nat.ptr(F), F.stride(0), F.shape[1], nat.ptr(edges), edges.shape[0], nat.ptr(rr),
+                                                             nat.ptr(g), nat.ptr(gF), gF.stride(0), nat.current_stream()))
+        if rr is not None and ctx.needs_input_grad[2]:
+            gr = (g[:, None] * F[edges[:, 0]] * F[edges[:, 1]]).sum(0).reshape(ctx.r_shape)
+        return gF, None, gr
+
+
+def edge_scores(F: torch.Tensor, edges, r=None) -> torch.Tensor:
+    """Logits of the listed edges ([m, 2] node ids): <F[u], F[v]> or, with DistMult weights r [C, 1], <F[u] * F[v], r>."""
+    nat.require_cuda(F, r)
+    e = torch.as_tensor(np.asarray(edges) if not isinstance(edges, torch.Tensor) else edges, dtype=torch.int64).reshape(-1, 2).to(F.device).contiguous()
+    return _EdgeScores.apply(F, e, r)

@@ -236,6 +236,15 @@ int gnx_halo_plan_layout(gnx_halo_plan_t plan, int64_t *n_buf, int64_t *local_ro
 int gnx_halo_pack(gnx_halo_plan_t plan, const float *d_X, int64_t ldx, int64_t C, float *d_send, int64_t lds, void *stream);
 int gnx_halo_exchange(gnx_halo_plan_t plan, void *nccl_comm, const float *d_send, float *d_X, int64_t C, void *stream);
 
+/* The link head, LinkPrediction.predict / loss (gnntf/core/gnn/graph_predictor.py:122-126, 136-144): the logit of every listed
+ * edge, d_out[i] = sum_c F[u_i, c] * F[v_i, c] * (d_r[c] or 1) -- gather of both endpoint rows + product + (DistMult) weights
+ * + reduction in one launch; d_edges int64 [m, 2].  Synchronises the stream (out-of-range endpoints -> GNX_ERR_INVALID).
+ * gnx_edge_scores_backward: d_grad_F[u_i, :] += g_i * F[v_i, :] * r and the mirror for v_i (caller zero-fills d_grad_F). */
+int gnx_edge_scores(const float *d_F, int64_t ldf, int64_t n_rows, int64_t C, const int64_t *d_edges, int64_t m,
+                    const float *d_r, float *d_out, void *stream);
+int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t C, const int64_t *d_edges, int64_t m, const float *d_r,
+                             const float *d_grad_out, float *d_grad_F, int64_t ldg, void *stream);
+
 /* Halo packing for the vertex-partitioned path: out[r,:] = X[idx[r],:], idx int64 [n_idx]. */
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,
                     float *d_out, int64_t ldo, void *stream);

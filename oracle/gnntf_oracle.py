@@ -379,3 +379,60 @@ def coo_to_csr_coalesced(indices, values, shape):
     np.add.at(rowptr, rows + 1, 1)
     rowptr = np.cumsum(rowptr)
     return rowptr, cols, vals
+
+
+# --------------------------------------------------------------------------------------
+# (f4 tail)  NGCFLayer  (gnntf/core/gnn/architectures/gcn.py:116-135)  and the link head
+#            (gnntf/core/gnn/graph_predictor.py:101-151)
+# --------------------------------------------------------------------------------------
+def leaky_relu(x, slope=0.2):
+    """tf.nn.leaky_relu with its default alpha = 0.2 (gcn.py:117)."""
+    return np.where(x > 0, x, x * x.dtype.type(slope))
+
+
+def l2_normalize_rows(x, eps=1e-12):
+    """tf.math.l2_normalize(x, axis=1): x / sqrt(max(sum(x^2), eps))."""
+    return x / np.sqrt(np.maximum((x * x).sum(axis=1, keepdims=True), eps))
+
+
+def ngcf_layer_eval(indices, values, shape, X, W1, b1, W2, b2, dtype=np.float64):
+    """gcn.py:130-135 in eval mode: A = bipartite-normalised adjacency (gnn.py:43-45, taken at build time gcn.py:127);
+    out = l2_normalize(leaky_relu((X * A.X).W1 + b1) + leaky_relu((A.X).W2 + b2))."""
+    ai, av = get_adjacency(indices, values, shape, normalized="bipartite", training=False, dtype=dtype)
+    X = np.asarray(X).astype(dtype)
+    agg = sparse_dense_matmul(ai, av, shape, X)
+    out = leaky_relu((X * agg) @ W1.astype(dtype) + b1.astype(dtype)) + leaky_relu(agg @ W2.astype(dtype) + b2.astype(dtype))
+    return l2_normalize_rows(out)
+
+
+def link_logits(features, edges, r=None, similarity="dot"):
+    """graph_predictor.py:122-126: sum over columns of F[u] * F[v] (optionally through the DistMult weights r [C, 1])."""
+    F = np.asarray(features)
+    if similarity == "cos":
+        F = l2_normalize_rows(F)
+    edges = np.asarray(edges)
+    prod = F[edges[:, 0]] * F[edges[:, 1]]
+    return prod.sum(axis=1) if r is None else (prod @ np.asarray(r)).reshape(-1)
+
+
+def link_loss_diff(features, edges, r=None, similarity="dot"):
+    """graph_predictor.py:138-141: -mean(log_sigmoid(logit[0::2] - logit[1::2]))."""
+    z = link_logits(features, edges, r, similarity)
+    d = z[0::2] - z[1::2]
+    return float(np.mean(np.log1p(np.exp(-np.abs(d))) + np.maximum(-d, 0)))
+
+
+def link_loss_bce(features, edges, labels, r=None, similarity="dot"):
+    """graph_predictor.py:142-146: BinaryCrossentropy(from_logits=True), mean over the edges."""
+    z = link_logits(features, edges, r, similarity)
+    y = np.asarray(labels, dtype=z.dtype).reshape(-1)
+    return float(np.mean(np.maximum(z, 0) - z * y + np.log1p(np.exp(-np.abs(z)))))
+
+
+def auc_by_pairs(labels, scores):
+    """Area under the ROC curve from its definition: P(score+ > score-) + 0.5 P(tie) over all positive/negative pairs
+    (what sklearn's roc_curve + auc integrate, measures.py:17-19)."""
+    labels, scores = np.asarray(labels).reshape(-1), np.asarray(scores, dtype=np.float64).reshape(-1)
+    pos, neg = scores[labels == 1], scores[labels != 1]
+    wins = (pos[:, None] > neg[None, :]).sum() + 0.5 * (pos[:, None] == neg[None, :]).sum()
+    return float(wins / (len(pos) * len(neg)))

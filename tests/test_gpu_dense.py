@@ -177,3 +177,88 @@ def test_sparse_input_features(gnntf):
     assert a.shape == (shape[0], 7) and bool(torch.isfinite(a).all())
     dense_X = rng.standard_normal((shape[0], 30)).astype(np.float32)
     assert gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), dense_X, num_classes=7)._input_features().__class__ is torch.Tensor
+
+
+def test_link_head_edge_scores(gnntf):
+    """gnx_edge_scores (graph_predictor.py:122-126): logits of listed edges in one launch, with and without the DistMult
+    weights, forward against float64 numpy and backward against torch autograd."""
+    rng = np.random.default_rng(14)
+    for C in (1, 5, 16, 40, 128):
+        n, m = 3000, 5000
+        F = rng.standard_normal((n, C)).astype(np.float32)
+        edges = rng.integers(0, n, size=(m, 2))
+        r = (rng.random((C, 1)) + 0.5).astype(np.float32)
+        for weights in (None, r):
+            Ft = dev(F).requires_grad_()
+            rt = None if weights is None else dev(weights).requires_grad_()
+            z = gnntf.edge_scores(Ft, edges, rt)
+            want = orc.link_logits(F.astype(np.float64), edges, None if weights is None else weights.astype(np.float64))
+            np.testing.assert_allclose(z.detach().cpu().numpy(), want, rtol=RTOL, atol=1e-4)
+            g = rng.standard_normal(m).astype(np.float32)
+            z.backward(dev(g))
+            Fr = dev(F).requires_grad_()
+            rr = None if weights is None else dev(weights).requires_grad_()
+            prod = Fr[dev(edges[:, 0])] * Fr[dev(edges[:, 1])]
+            (prod.sum(1) if rr is None else (prod @ rr).reshape(-1)).backward(dev(g))
+            np.testing.assert_allclose(Ft.grad.cpu().numpy(), Fr.grad.cpu().numpy(), rtol=1e-3, atol=1e-4)
+            if rt is not None:
+                np.testing.assert_allclose(rt.grad.cpu().numpy(), rr.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    with pytest.raises(Exception, match="out of range"):
+        gnntf.edge_scores(dev(F), [[0, n]])
+    # through the task API, both losses and both similarities
+    labels = rng.integers(0, 2, size=200).astype(np.float32); labels[:2] = [0, 1]
+    e = edges[:200]
+    Fd = dev(F)
+    for sim in ("dot", "cos"):
+        task = gnntf.LinkPrediction(e, labels, similarity=sim)
+        assert abs(float(task.loss(Fd)) - orc.link_loss_diff(F.astype(np.float64), e, similarity=sim)) < 1e-4
+        bce = gnntf.LinkPrediction(e, labels, similarity=sim, loss="bce")
+        assert abs(float(bce.loss(Fd)) - orc.link_loss_bce(F.astype(np.float64), e, labels, similarity=sim)) < 1e-4
+        z = orc.link_logits(F.astype(np.float64), e, similarity=sim)
+        assert abs(task.evaluate(Fd) - orc.auc_by_pairs(labels, 1 / (1 + np.exp(-z)))) < 1e-4
+
+
+def test_ngcf_model(gnntf):
+    """NGCFLayer / NGCF (gcn.py:116-154) over the bipartite-normalised propagation: layer output against the oracle, the
+    model's axis-0 stacked output, and a few epochs of link-prediction training through architecture.train()."""
+    import networkx as nx
+    import random
+    rng = np.random.default_rng(21)
+    n, F = 400, 12
+    G = nx.Graph(); G.add_nodes_from(range(n))
+    for u, v in rng.integers(0, n, size=(1600, 2)):
+        if u != v:
+            G.add_edge(int(u), int(v))
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    gnntf.set_seed(2)
+    model = gnntf.NGCF(gnntf.graph2adj(G), X, num_classes=8, dropout=0.0)
+    model.reset()
+    layers = [l for l in model.layers() if isinstance(l, gnntf.NGCFLayer)]
+    assert len(layers) == 3 and model.layers()[-1].__class__ is gnntf.Concatenate
+    model.training_mode(False)
+    with torch.no_grad():
+        out = model(model.features)
+    assert out.shape == (3 * n, 8)                                            # the reference's axis-0 stacking (layers.py:98-101)
+    coo = gnntf.graph2adj(G)
+    idx, vals = coo.indices.cpu().numpy(), coo.values.cpu().numpy()
+    l0 = layers[0]
+    want = orc.ngcf_layer_eval(idx, vals, (n, n), X, *(t.detach().cpu().numpy() for t in (l0.W1, l0.b1, l0.W2, l0.b2)))
+    np.testing.assert_allclose(out[:n].cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(np.linalg.norm(out[:n].cpu().numpy(), axis=1), 1.0, rtol=1e-5)
+    # training: pairwise loss over a negative sampler, early stopping on held-out edges, AUC above chance
+    random.seed(0)
+    edges = np.array(list(G.edges()))
+    perm = rng.permutation(len(edges))
+    train, valid = edges[perm[:1000]], edges[perm[1000:1200]]
+    model.train(train=gnntf.LinkPrediction(gnntf.negative_sampling(train, G)),
+                valid=gnntf.LinkPrediction(*gnntf.negative_sampling(valid, G)()), epochs=30, patience=30)
+    test_edges, test_labels = gnntf.negative_sampling(edges[perm[1200:1400]], G)()
+    scores = model.predict(gnntf.LinkPrediction(test_edges))
+    assert scores.shape[0] == len(test_labels) and gnntf.auc(test_labels, scores) > 0.5
+    # zero-width features + structural embeddings (demos/development/library_recommendation.py:45-47)
+    emb = gnntf.NGCF(gnntf.graph2adj(G), np.zeros((n, 0), dtype=np.float32), num_classes=8,
+                     preprocessor=gnntf.Structural(dims=16, regularize=0, bipartite=100))
+    emb.reset()
+    emb.training_mode(False)
+    with torch.no_grad():
+        assert emb(emb.features).shape == (3 * n, 8)
