@@ -84,6 +84,70 @@ __global__ __launch_bounds__(256) void k_colsum_long(const int64_t *__restrict__
     if (threadIdx.x == 0) out[j] = red[0];
 }
 
+// Column sums of NS consecutive dropout streams in ONE pass over the transposed structure (no duplicate entries): the K
+// iterations of a training step each drop the edges independently, so their column sums differ only in the hash -- the
+// structure and the raw values are read once for all of them.  Same lane mapping and reduction tree as k_colsum_short / _long,
+// so every stream's sums are bit for bit what the single-stream kernels give.  out[s * n_cols + j].
+template <int NS>
+__global__ void k_colsum_short_multi(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
+                                     const float *__restrict__ t_raw, Drop d, int64_t n_cols, float *__restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = gid >> 3;
+    const int sub = (int)(gid & 7);
+    float acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+    bool is_long = false;
+    if (j < n_cols) {
+        const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
+        is_long = (e - b) > LONG_ROW;
+        if (!is_long)
+            for (int64_t p = b + sub; p < e; p += 8) {
+                const float v = t_raw[p] * d.scale;
+                const uint64_t row = (uint64_t)t_colidx[p];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, d.stream + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
+            }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float a = acc[s];
+        a += __shfl_xor(a, 4);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 1);
+        if (j < n_cols && sub == 0 && !is_long) out[(int64_t)s * n_cols + j] = a;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_colsum_long_multi(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
+                                                           const float *__restrict__ t_raw, Drop d, const int32_t *__restrict__ long_rows,
+                                                           int64_t n_cols, float *__restrict__ out) {
+    __shared__ float red[256];
+    const int32_t j = long_rows[blockIdx.x];
+    const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
+    float acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) {
+        const float v = t_raw[p] * d.scale;
+        const uint64_t row = (uint64_t)t_colidx[p];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, d.stream + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        __syncthreads();
+        red[threadIdx.x] = acc[s];
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[(int64_t)s * n_cols + j] = red[0];
+    }
+}
+
 // gnn.py:41 / :44 with optional "+I before" folded in as +1 on every column sum
 __global__ void k_degree_scale(float *__restrict__ d, int64_t n, int normalized, float eye) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,6 +231,48 @@ int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t str
     if (t.n_long > 0) {
         if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
         else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
+    }
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_graph_colsum_streams(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t first_stream, int n_streams, float *d_colsum_out,
+                             void *stream) {
+    GNX_CHECK_ARG(g != nullptr && d_colsum_out != nullptr, "gnx_graph_colsum_streams: NULL argument");
+    GNX_CHECK_ARG(n_streams >= 1 && n_streams <= 4096, "gnx_graph_colsum_streams: bad stream count %d", n_streams);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = g->a.n_cols;
+    if (g->has_dups || dropout_p <= 0.f) {              // entry lists / no dropout: one stream at a time through the general kernels
+        for (int k = 0; k < n_streams; ++k) {
+            int rc = gnx_graph_colsum(g, dropout_p, seed, first_stream + k, d_colsum_out + (int64_t)k * n, stream);
+            if (rc != GNX_OK) return rc;
+        }
+        return GNX_OK;
+    }
+    int rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    const Csr &t = g->t;
+    if (t.n_rows == 0) return GNX_OK;
+    const unsigned nb = blocks_for(t.n_rows * 8);
+    for (int k0 = 0; k0 < n_streams;) {                 // batches of 8 / 4 / 2 / 1 streams per pass
+        Drop d;
+        rc = make_drop(g, dropout_p, seed, first_stream + k0, d);
+        if (rc != GNX_OK) return rc;
+        float *out = d_colsum_out + (int64_t)k0 * n;
+        const int left = n_streams - k0;
+#define GNX_MULTI(NS)                                                                                                                  \
+        do {                                                                                                                           \
+            hipLaunchKernelGGL(k_colsum_short_multi<NS>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, t.n_rows, out);    \
+            if (t.n_long > 0)                                                                                                          \
+                hipLaunchKernelGGL(k_colsum_long_multi<NS>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, \
+                                   t.long_rows, t.n_rows, out);                                                                        \
+            k0 += NS;                                                                                                                  \
+        } while (0)
+        if (left >= 8) GNX_MULTI(8);
+        else if (left >= 4) GNX_MULTI(4);
+        else if (left >= 2) GNX_MULTI(2);
+        else GNX_MULTI(1);
+#undef GNX_MULTI
     }
     GNX_HIP(hipGetLastError());
     return GNX_OK;

@@ -132,16 +132,12 @@ class PPRLoop(Layer):
         if self.graph_dropout != 0 and architecture.is_training():
             seed, first = architecture._next_mask_stream(self.iterations)
             graph, p = architecture.graph, self.graph_dropout
-            kept = dict()                                                  # the N degree scales of an iteration serve its backward too
-
-            def make_adj(k, bwd=False):
-                if k in kept:
-                    return kept.pop(k) if bwd else kept[k]
-                adj = sparse.dropped_adjacency(graph, p, seed, first + k)
-                if isinstance(adj, sparse.DroppedAdjacency):
-                    kept[k] = adj                                          # N floats: cheap to keep until the backward
-                    return adj
-                return sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=True) if bwd else adj
+            if sparse.can_fuse_dropout(graph, p):
+                # the degree scales of all K iterations in one pass over the structure; kept (K x N floats) for the backward
+                scales = sparse.dropped_degree_scales(graph, p, seed, first, self.iterations)
+                make_adj = lambda k, bwd=False: sparse.dropped_adjacency(graph, p, seed, first + k, D=scales[k])
+            else:
+                make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
         else:
             adj = architecture.get_adjacency(self.graph_dropout)
             make_adj = lambda k, bwd=False: adj

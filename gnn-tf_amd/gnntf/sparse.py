@@ -149,13 +149,10 @@ class DroppedAdjacency(Adjacency):
     (D[row] * dropout(raw)) * D[col] from the counter RNG while they gather (gnx_spmm_dropped) -- forward and transposed, bit
     for bit the values gnx_graph_normalize would have written.  ``.vals`` materialises them on demand (custom layers)."""
 
-    def __init__(self, graph: DeviceGraph, p, seed, stream_id):
+    def __init__(self, graph: DeviceGraph, p, seed, stream_id, D=None):
         super().__init__(graph, None, None, None)
         self.p, self.seed, self.stream_id = float(p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFFFFFFFFFF
-        self.D = torch.empty(graph.n_cols, dtype=torch.float32, device=graph.device)
-        with torch.cuda.device(graph.device):
-            nat.check(nat.lib().gnx_graph_colsum(graph.handle, self.p, self.seed, self.stream_id, nat.ptr(self.D), nat.current_stream()))
-            nat.check(nat.lib().gnx_degree_scale(nat.ptr(self.D), self.D.numel(), nat.NORM["symmetric"], 0, nat.current_stream()))
+        self.D = D if D is not None else dropped_degree_scales(graph, self.p, self.seed, self.stream_id, 1)[0]
         self._vals = None
 
     @property
@@ -174,11 +171,26 @@ class DroppedAdjacency(Adjacency):
         return self.vals_t
 
 
-def dropped_adjacency(graph: DeviceGraph, p, seed, stream_id) -> Adjacency:
+def dropped_degree_scales(graph: DeviceGraph, p, seed, first_stream, n_streams) -> torch.Tensor:
+    """D = divide_no_nan(1, sqrt(column sums of the dropped values)) (gnn.py:41) for ``n_streams`` consecutive dropout streams,
+    [n_streams, n]: ONE pass over the structure for all of them (gnx_graph_colsum_streams)."""
+    D = torch.empty((n_streams, graph.n_cols), dtype=torch.float32, device=graph.device)
+    with torch.cuda.device(graph.device):
+        nat.check(nat.lib().gnx_graph_colsum_streams(graph.handle, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                     int(first_stream) & 0xFFFFFFFFFFFFFFFF, int(n_streams), nat.ptr(D), nat.current_stream()))
+        nat.check(nat.lib().gnx_degree_scale(nat.ptr(D), D.numel(), nat.NORM["symmetric"], 0, nat.current_stream()))
+    return D
+
+
+def can_fuse_dropout(graph: DeviceGraph, p) -> bool:
+    return graph.nnz_entries == graph.nnz and graph.n_rows == graph.n_cols and p > 0
+
+
+def dropped_adjacency(graph: DeviceGraph, p, seed, stream_id, D=None) -> Adjacency:
     """A training iteration's adjacency: the fused form when the graph allows it (no duplicate COO entries, square),
-    else the materialised one."""
-    if graph.nnz_entries == graph.nnz and graph.n_rows == graph.n_cols and p > 0:
-        return DroppedAdjacency(graph, p, seed, stream_id)
+    else the materialised one.  ``D``: its degree scales if already known (dropped_degree_scales)."""
+    if can_fuse_dropout(graph, p):
+        return DroppedAdjacency(graph, p, seed, stream_id, D=D)
     return normalize(graph, "symmetric", "none", p, seed, stream_id)
 
 

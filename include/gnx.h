@@ -111,6 +111,11 @@ int gnx_graph_normalize_t(gnx_graph_t g, int normalized, int add_eye, float drop
  *           may be NULL (= 1).  (gnn.py:42,45) */
 int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id,
                      float *d_colsum_out, void *stream);
+/* gnx_graph_colsum for n_streams consecutive dropout streams (first_stream, first_stream + 1, ...) in one pass over the
+ * structure: the K iterations of a training step drop their edges independently but share everything else.
+ * d_colsum_out is [n_streams, n_cols]; every row is bit for bit what gnx_graph_colsum gives for that stream. */
+int gnx_graph_colsum_streams(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t first_stream, int n_streams,
+                             float *d_colsum_out, void *stream);
 int gnx_degree_scale(float *d_deg, int64_t n, int normalized, int add_eye_before, void *stream);
 int gnx_graph_scale_values(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id,
                            const float *d_row_scale, const float *d_col_scale, float *d_vals_out,

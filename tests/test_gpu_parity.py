@@ -434,6 +434,32 @@ def test_dropped_adjacency_fused_into_spmm_bitwise(gnntf, C):
     assert not isinstance(gnntf.sparse.dropped_adjacency(dup, 0.5, 1, 1), DroppedAdjacency)
 
 
+def test_degree_scales_of_k_streams_in_one_pass(gnntf):
+    """gnx_graph_colsum_streams: the column sums of K dropout streams from one pass over the structure == K separate
+    gnx_graph_colsum calls, bit for bit (hub columns included; duplicates take the per-stream path), and against the oracle."""
+    from gnntf import _native as nat
+    n = 3000
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 25000, seed=3)
+    hub = np.random.default_rng(4).choice(np.arange(1, n), size=1500, replace=False)
+    coo = np.unique(np.concatenate([coo, np.stack([hub, np.zeros_like(hub)], 1)]), axis=0)       # column 0: > 512 entries
+    vals = (np.random.default_rng(5).random(len(coo)) + 0.5).astype(np.float32)
+    for with_dups in (False, True):
+        c, v = (np.concatenate([coo, coo[:40]]), np.concatenate([vals, vals[:40]])) if with_dups else (coo, vals)
+        g = make_graph(gnntf, c, v, shape)
+        for K in (1, 3, 10, 13):
+            got = torch.empty((K, n), device="cuda")
+            nat.check(nat.lib().gnx_graph_colsum_streams(g.handle, 0.5, 99, 7, K, nat.ptr(got), nat.current_stream()))
+            for k in range(K):
+                one = torch.empty(n, device="cuda")
+                nat.check(nat.lib().gnx_graph_colsum(g.handle, 0.5, 99, 7 + k, nat.ptr(one), nat.current_stream()))
+                assert torch.equal(got[k], one), (with_dups, K, k)
+        keep = orc.keep_mask(c, 0.5, 99, 8)
+        want = orc.sparse_reduce_sum_axis0(c, np.where(keep, v * np.float32(2), np.float32(0)).astype(np.float64), shape)
+        np.testing.assert_allclose(got[1].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    D = gnntf.sparse.dropped_degree_scales(make_graph(gnntf, coo, vals, shape), 0.5, 99, 7, 4)
+    assert D.shape == (4, n) and bool(torch.isfinite(D).all())
+
+
 @pytest.mark.parametrize("C", [7, 64])
 def test_backward_matches_oracle(gnntf, C):
     coo, vals, shape = graphs.random_coo(400, 400, 5000, seed=31, weighted=True)
