@@ -131,13 +131,13 @@ __device__ __forceinline__ float group16_sum(float v) {
 
 __global__ __launch_bounds__(256) void k_node_ce_fwd(const float *__restrict__ logits, int64_t ldl, int C, int64_t n_rows,
                                                       const int64_t *__restrict__ nodes, const int64_t *__restrict__ labels, int64_t m,
-                                                      float *__restrict__ loss, int *__restrict__ bad) {
+                                                      float *__restrict__ loss) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (i >= m) return;
     const int64_t node = nodes[i], label = labels[i];
-    if (node < 0 || node >= n_rows || label < 0 || label >= C) {
-        if (sub == 0) { atomicExch(bad, 1); loss[i] = 0.f; }
+    if (node < 0 || node >= n_rows || label < 0 || label >= C) {      // never read out of bounds: the loss of such an item is NaN
+        if (sub == 0) loss[i] = NAN;
         return;
     }
     const float *__restrict__ x = logits + node * ldl;
@@ -151,13 +151,14 @@ __global__ __launch_bounds__(256) void k_node_ce_fwd(const float *__restrict__ l
 }
 
 // d logits[node_i, :] += scale * (softmax(x) - onehot(label)); atomics because a node may be listed twice
-__global__ __launch_bounds__(256) void k_node_ce_bwd(const float *__restrict__ logits, int64_t ldl, int C, const int64_t *__restrict__ nodes,
-                                                      const int64_t *__restrict__ labels, int64_t m, const float *__restrict__ gout, float inv_m,
-                                                      float *__restrict__ grad, int64_t ldg) {
+__global__ __launch_bounds__(256) void k_node_ce_bwd(const float *__restrict__ logits, int64_t ldl, int C, int64_t n_rows,
+                                                      const int64_t *__restrict__ nodes, const int64_t *__restrict__ labels, int64_t m,
+                                                      const float *__restrict__ gout, float inv_m, float *__restrict__ grad, int64_t ldg) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (i >= m) return;
     const int64_t node = nodes[i], label = labels[i];
+    if (node < 0 || node >= n_rows || label < 0 || label >= C) return;
     const float *__restrict__ x = logits + node * ldl;
     float mx = -INFINITY;
     for (int c = sub; c < C; c += 16) mx = fmaxf(mx, x[c]);
@@ -205,13 +206,13 @@ __global__ __launch_bounds__(256) void k_mean(const float *__restrict__ v, int64
 
 // first index of the row maximum (tf.argmax / np.argmax tie rule)
 __global__ __launch_bounds__(256) void k_node_argmax(const float *__restrict__ logits, int64_t ldl, int C, int64_t n_rows,
-                                                      const int64_t *__restrict__ nodes, int64_t m, int64_t *__restrict__ out, int *__restrict__ bad) {
+                                                      const int64_t *__restrict__ nodes, int64_t m, int64_t *__restrict__ out) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (i >= m) return;
     const int64_t node = nodes ? nodes[i] : i;
-    if (node < 0 || node >= n_rows) {
-        if (sub == 0) { atomicExch(bad, 1); out[i] = 0; }
+    if (node < 0 || node >= n_rows) {                                   // out of range: -1
+        if (sub == 0) out[i] = -1;
         return;
     }
     const float *__restrict__ x = logits + node * ldl;
@@ -233,13 +234,13 @@ __global__ __launch_bounds__(256) void k_node_argmax(const float *__restrict__ l
 // ---- link head: logit_i = sum_c F[u_i, c] * F[v_i, c] * (r[c] or 1)   (graph_predictor.py:122-126) ---------------------
 __global__ __launch_bounds__(256) void k_edge_scores(const float *__restrict__ F, int64_t ldf, int C, int64_t n_rows,
                                                       const int64_t *__restrict__ edges, int64_t m, const float *__restrict__ r,
-                                                      float *__restrict__ out, int *__restrict__ bad) {
+                                                      float *__restrict__ out) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (i >= m) return;
     const int64_t u = edges[2 * i], v = edges[2 * i + 1];
-    if (u < 0 || u >= n_rows || v < 0 || v >= n_rows) {
-        if (sub == 0) { atomicExch(bad, 1); out[i] = 0.f; }
+    if (u < 0 || u >= n_rows || v < 0 || v >= n_rows) {                 // out of range: NaN
+        if (sub == 0) out[i] = NAN;
         return;
     }
     const float *__restrict__ fu = F + u * ldf, *__restrict__ fv = F + v * ldf;
@@ -250,13 +251,14 @@ __global__ __launch_bounds__(256) void k_edge_scores(const float *__restrict__ F
 }
 
 // dF[u_i, :] += g_i * F[v_i, :] * r,  dF[v_i, :] += g_i * F[u_i, :] * r   (atomics: endpoints repeat across edges)
-__global__ __launch_bounds__(256) void k_edge_scores_bwd(const float *__restrict__ F, int64_t ldf, int C, const int64_t *__restrict__ edges,
-                                                          int64_t m, const float *__restrict__ r, const float *__restrict__ g,
-                                                          float *__restrict__ dF, int64_t ldg) {
+__global__ __launch_bounds__(256) void k_edge_scores_bwd(const float *__restrict__ F, int64_t ldf, int C, int64_t n_rows,
+                                                          const int64_t *__restrict__ edges, int64_t m, const float *__restrict__ r,
+                                                          const float *__restrict__ g, float *__restrict__ dF, int64_t ldg) {
     const int sub = threadIdx.x & 15;
     const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (i >= m) return;
     const int64_t u = edges[2 * i], v = edges[2 * i + 1];
+    if (u < 0 || u >= n_rows || v < 0 || v >= n_rows) return;
     const float gi = g[i];
     for (int c = sub; c < C; c += 16) {
         const float w = gi * (r ? r[c] : 1.0f);
@@ -316,35 +318,25 @@ int gnx_node_ce(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, c
     GNX_CHECK_ARG(m >= 1 && C >= 1 && n_rows >= 1 && ldl >= C, "gnx_node_ce: bad sizes");
     GNX_CHECK_ARG(d_logits && d_nodes && d_labels && d_loss_per_node && d_mean_loss, "gnx_node_ce: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    int *bad = nullptr;
-    GNX_HIP(hipMalloc((void **)&bad, sizeof(int)));
-    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{bad};
-    GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_node_ce_fwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_logits, ldl, (int)C, n_rows, d_nodes, d_labels, m,
-                       d_loss_per_node, bad);
-    if (m > 4096) {
-        float *partial = nullptr;
-        GNX_HIP(hipMalloc((void **)&partial, MEAN_BLOCKS * sizeof(float)));
+                       d_loss_per_node);
+    if (m > 4096) {      // two-level mean; the partial sums live in the scratch tail of d_loss_per_node
+        float *partial = d_loss_per_node + m;
         hipLaunchKernelGGL(k_mean_partial, dim3(MEAN_BLOCKS), dim3(256), 0, s, d_loss_per_node, m, partial);
         hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, s, partial, (int64_t)MEAN_BLOCKS, m, d_mean_loss);
-        GNX_HIP(hipStreamSynchronize(s));
-        (void)hipFree(partial);
     } else {
         hipLaunchKernelGGL(k_mean, dim3(1), dim3(256), 0, s, d_loss_per_node, m, m, d_mean_loss);
     }
-    int h_bad = 0;
-    GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
-    GNX_HIP(hipStreamSynchronize(s));
-    GNX_CHECK_ARG(h_bad == 0, "gnx_node_ce: a node id or a label is out of range");
+    GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
 
-int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t C, const int64_t *d_nodes, const int64_t *d_labels, int64_t m,
-                         const float *d_grad_loss, float *d_grad_logits, int64_t ldg, void *stream) {
-    GNX_CHECK_ARG(m >= 1 && C >= 1 && ldl >= C && ldg >= C, "gnx_node_ce_backward: bad sizes");
+int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, const int64_t *d_labels,
+                         int64_t m, const float *d_grad_loss, float *d_grad_logits, int64_t ldg, void *stream) {
+    GNX_CHECK_ARG(m >= 1 && C >= 1 && n_rows >= 1 && ldl >= C && ldg >= C, "gnx_node_ce_backward: bad sizes");
     GNX_CHECK_ARG(d_logits && d_nodes && d_labels && d_grad_loss && d_grad_logits, "gnx_node_ce_backward: NULL pointer");
-    hipLaunchKernelGGL(k_node_ce_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_logits, ldl, (int)C, d_nodes,
-                       d_labels, m, d_grad_loss, 1.0f / (float)m, d_grad_logits, ldg);
+    hipLaunchKernelGGL(k_node_ce_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_logits, ldl, (int)C, n_rows,
+                       d_nodes, d_labels, m, d_grad_loss, 1.0f / (float)m, d_grad_logits, ldg);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
@@ -354,26 +346,19 @@ int gnx_edge_scores(const float *d_F, int64_t ldf, int64_t n_rows, int64_t C, co
     GNX_CHECK_ARG(m >= 0 && C >= 1 && n_rows >= 0 && ldf >= C, "gnx_edge_scores: bad sizes");
     if (m == 0) return GNX_OK;
     GNX_CHECK_ARG(d_F && d_edges && d_out, "gnx_edge_scores: NULL pointer");
-    hipStream_t s = (hipStream_t)stream;
-    int *bad = nullptr;
-    GNX_HIP(hipMalloc((void **)&bad, sizeof(int)));
-    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{bad};
-    GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_edge_scores, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_F, ldf, (int)C, n_rows, d_edges, m, d_r, d_out, bad);
-    int h_bad = 0;
-    GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
-    GNX_HIP(hipStreamSynchronize(s));
-    GNX_CHECK_ARG(h_bad == 0, "gnx_edge_scores: an edge endpoint is out of range");
+    hipLaunchKernelGGL(k_edge_scores, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_F, ldf, (int)C, n_rows, d_edges, m,
+                       d_r, d_out);
+    GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
 
-int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t C, const int64_t *d_edges, int64_t m, const float *d_r,
+int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t n_rows, int64_t C, const int64_t *d_edges, int64_t m, const float *d_r,
                              const float *d_grad_out, float *d_grad_F, int64_t ldg, void *stream) {
     GNX_CHECK_ARG(m >= 0 && C >= 1 && ldf >= C && ldg >= C, "gnx_edge_scores_backward: bad sizes");
     if (m == 0) return GNX_OK;
     GNX_CHECK_ARG(d_F && d_edges && d_grad_out && d_grad_F, "gnx_edge_scores_backward: NULL pointer");
-    hipLaunchKernelGGL(k_edge_scores_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_F, ldf, (int)C, d_edges, m,
-                       d_r, d_grad_out, d_grad_F, ldg);
+    hipLaunchKernelGGL(k_edge_scores_bwd, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_F, ldf, (int)C, n_rows, d_edges,
+                       m, d_r, d_grad_out, d_grad_F, ldg);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
@@ -383,16 +368,9 @@ int gnx_node_argmax(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t 
     GNX_CHECK_ARG(m >= 0 && C >= 1 && n_rows >= 0 && ldl >= C, "gnx_node_argmax: bad sizes");
     if (m == 0) return GNX_OK;
     GNX_CHECK_ARG(d_logits && d_out, "gnx_node_argmax: NULL pointer");
-    hipStream_t s = (hipStream_t)stream;
-    int *bad = nullptr;
-    GNX_HIP(hipMalloc((void **)&bad, sizeof(int)));
-    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{bad};
-    GNX_HIP(hipMemsetAsync(bad, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_node_argmax, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s, d_logits, ldl, (int)C, n_rows, d_nodes, m, d_out, bad);
-    int h_bad = 0;
-    GNX_HIP(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
-    GNX_HIP(hipStreamSynchronize(s));
-    GNX_CHECK_ARG(h_bad == 0, "gnx_node_argmax: a node id is out of range");
+    hipLaunchKernelGGL(k_node_argmax, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_logits, ldl, (int)C, n_rows, d_nodes, m,
+                       d_out);
+    GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
 

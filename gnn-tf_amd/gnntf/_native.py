@@ -59,11 +59,12 @@ SIGNATURES = {
     "gnx_dense": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64,
                           c_void_p]),
     "gnx_node_ce": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "gnx_node_ce_backward": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+    "gnx_node_ce_backward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                      c_void_p]),
     "gnx_node_argmax": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "gnx_edge_scores": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "gnx_edge_scores_backward": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gnx_edge_scores_backward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_void_p]),
     "gnx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_graph_last_kernel": (c_char_p, [c_void_p]),
 }
@@ -99,8 +100,32 @@ def ptr(t):
 
 
 def current_stream():
+    """The raw hipStream_t of torch's current stream on the current device (the cheap accessor: this sits on every launch)."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+
+
+class on_device:
+    """``with on_device(t.device):`` -- makes the tensor's device current for the launch; free when it already is
+    (the usual case: one process per GPU)."""
+
+    __slots__ = ("index", "prev")
+
+    def __init__(self, device):
+        self.index = device.index
+
+    def __enter__(self):
+        import torch
+        self.prev = torch.cuda.current_device()
+        if self.index is None:
+            self.index = self.prev
+        if self.prev != self.index:
+            torch.cuda.set_device(self.index)
+
+    def __exit__(self, *exc):
+        if self.prev != self.index:
+            import torch
+            torch.cuda.set_device(self.prev)
 
 
 def require_cuda(*tensors):

@@ -62,19 +62,19 @@ class NativeBackend:
 
     def colsum(self, graph):
         out = torch.empty(graph.n_cols, dtype=torch.float32, device=graph.device)
-        with torch.cuda.device(graph.device):
+        with nat.on_device(graph.device):
             nat.check(nat.lib().gnx_graph_colsum(graph.handle, 0.0, 0, 0, nat.ptr(out), nat.current_stream()))
         return out
 
     def degree_scale(self, deg, normalized="symmetric"):
-        with torch.cuda.device(deg.device):
+        with nat.on_device(deg.device):
             nat.check(nat.lib().gnx_degree_scale(nat.ptr(deg), deg.numel(), nat.NORM[normalized], 0, nat.current_stream()))
         return deg
 
     def scale_values(self, graph, row_scale, col_scale):
         out = torch.empty(graph.nnz, dtype=torch.float32, device=graph.device)
         row_scale = row_scale.contiguous() if row_scale is not None else None
-        with torch.cuda.device(graph.device):
+        with nat.on_device(graph.device):
             nat.check(nat.lib().gnx_graph_scale_values(graph.handle, 0.0, 0, 0, nat.ptr(row_scale), nat.ptr(col_scale),
                                                        nat.ptr(out), nat.current_stream()))
         return out

@@ -70,7 +70,7 @@ class DeviceGraph:
                 raise Exception("DeviceGraph: CSR array lengths do not match the shape")
             self.device = rowptr.device
             self._keep = (rowptr.contiguous(), colidx.contiguous(), vals.contiguous())
-            with torch.cuda.device(self.device):
+            with nat.on_device(self.device):
                 nat.check(lib.gnx_graph_create_csr(shape[0], shape[1], self._keep[1].numel(), nat.ptr(self._keep[0]),
                                                    nat.ptr(self._keep[1]), nat.ptr(self._keep[2]), nat.current_stream(),
                                                    byref(self._h)))
@@ -83,7 +83,7 @@ class DeviceGraph:
             idx = coo.indices.to(device).contiguous()
             val = coo.values.to(device).contiguous()
             self.device = idx.device                        # with its index ("cuda" -> "cuda:0")
-            with torch.cuda.device(device):
+            with nat.on_device(device):
                 nat.check(lib.gnx_graph_create_coo(coo.dense_shape[0], coo.dense_shape[1], idx.shape[0], nat.ptr(idx),
                                                    nat.ptr(val), nat.current_stream(), byref(self._h)))
         n_rows, n_cols, nnz_e, nnz_c = c_int64(), c_int64(), c_int64(), c_int64()
@@ -101,7 +101,7 @@ class DeviceGraph:
         colidx = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
         vals = torch.empty(self.nnz, dtype=torch.float32, device=self.device)
         rows = torch.empty(self.nnz, dtype=torch.int32, device=self.device) if with_rows else None
-        with torch.cuda.device(self.device):
+        with nat.on_device(self.device):
             nat.check(nat.lib().gnx_graph_export(self._h, nat.ptr(rowptr), nat.ptr(colidx), nat.ptr(vals), nat.ptr(rows),
                                                  nat.current_stream()))
         return (rowptr, colidx, vals, rows) if with_rows else (rowptr, colidx, vals)
@@ -133,7 +133,7 @@ class Adjacency:
         """Values in transposed order, permuted once and kept (a constant adjacency is reused by every backward)."""
         if self.vals_t is None:
             out = torch.empty(self.graph.nnz, dtype=torch.float32, device=self.graph.device)
-            with torch.cuda.device(self.graph.device):
+            with nat.on_device(self.graph.device):
                 nat.check(nat.lib().gnx_graph_permute_values_t(self.graph.handle, nat.ptr(self.vals), nat.ptr(out), nat.current_stream()))
             self.vals_t = out
         return self.vals_t
@@ -175,7 +175,7 @@ def dropped_degree_scales(graph: DeviceGraph, p, seed, first_stream, n_streams) 
     """D = divide_no_nan(1, sqrt(column sums of the dropped values)) (gnn.py:41) for ``n_streams`` consecutive dropout streams,
     [n_streams, n]: ONE pass over the structure for all of them (gnx_graph_colsum_streams)."""
     D = torch.empty((n_streams, graph.n_cols), dtype=torch.float32, device=graph.device)
-    with torch.cuda.device(graph.device):
+    with nat.on_device(graph.device):
         nat.check(nat.lib().gnx_graph_colsum_streams(graph.handle, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                      int(first_stream) & 0xFFFFFFFFFFFFFFFF, int(n_streams), nat.ptr(D), nat.current_stream()))
         nat.check(nat.lib().gnx_degree_scale(nat.ptr(D), D.numel(), nat.NORM["symmetric"], 0, nat.current_stream()))
@@ -205,7 +205,7 @@ def normalize(graph: DeviceGraph, normalized="symmetric", add_eye="none", dropou
     vals = torch.empty(graph.nnz, dtype=torch.float32, device=graph.device)
     diag = torch.empty(graph.n_rows, dtype=torch.float32, device=graph.device) if add_eye != "none" else None
     fn = nat.lib().gnx_graph_normalize_t if transposed_only else nat.lib().gnx_graph_normalize
-    with torch.cuda.device(graph.device):
+    with nat.on_device(graph.device):
         nat.check(fn(graph.handle, nat.NORM[normalized], nat.EYE[add_eye], float(dropout), int(seed) & 0xFFFFFFFFFFFFFFFF,
                      int(stream_id) & 0xFFFFFFFFFFFFFFFF, nat.ptr(vals), nat.ptr(diag), nat.current_stream()))
     return Adjacency(graph, None, diag, vals_t=vals) if transposed_only else Adjacency(graph, vals, diag)
@@ -252,7 +252,7 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
         else:
             ldh0 = H0.stride(0)
     if isinstance(adj, DroppedAdjacency) and out_rows is None:       # weights produced inside the kernel
-        with torch.cuda.device(X.device):
+        with nat.on_device(X.device):
             nat.check(nat.lib().gnx_spmm_dropped(g.handle, nat.ptr(adj.D), adj.p, adj.seed, adj.stream_id, 1 if transposed else 0,
                                                  nat.ptr(X), X.stride(0), C, nat.ptr(H0), ldh0, float(beta), float(alpha), int(act),
                                                  nat.ptr(out), out.stride(0), nat.current_stream()))
@@ -263,7 +263,7 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
         if adj.vals is None and adj.vals_t is not None:
             raise Exception("spmm: this adjacency only holds transposed-order values")
         fn, values = nat.lib().gnx_spmm, adj.vals
-    with torch.cuda.device(X.device):
+    with nat.on_device(X.device):
         if out_rows is not None:                                # result row i -> out[out_rows[i]]
             if transposed or out_rows.dtype != torch.int32 or out_rows.numel() != rows_out or not out_rows.is_cuda:
                 raise Exception("spmm: bad output row map")
@@ -297,7 +297,7 @@ def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out, act=nat.ACT_NONE)
         if tuple(H0.shape) != tuple(out.shape):
             raise Exception("spmm: H0 shape mismatch")
         ldh0 = H0.stride(0)
-    with torch.cuda.device(X.device):
+    with nat.on_device(X.device):
         nat.check(nat.lib().gnx_spmm_rows(g.handle, nat.ptr(adj.vals), nat.ptr(X), X.stride(0), C, nat.ptr(H0), ldh0, float(beta),
                                           float(alpha), int(act), nat.ptr(rows), nat.ptr(out), out.stride(0),
                                           nat.current_stream()))
@@ -417,7 +417,7 @@ def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations
         raise Exception("appnp_propagate: needs a square graph matching H0")
     out = torch.empty_like(H0)
     work = torch.empty_like(H0) if iterations > 1 else None
-    with torch.cuda.device(H0.device):
+    with nat.on_device(H0.device):
         nat.check(nat.lib().gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(H0), float(a),
                                                 int(iterations), H0.shape[1], nat.ptr(out), nat.ptr(work),
                                                 nat.current_stream()))
@@ -430,7 +430,7 @@ def gather_rows(X: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     X = _as_f32_rows(X)
     idx = idx.to(torch.int64).contiguous()
     out = torch.empty((idx.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
-    with torch.cuda.device(X.device):
+    with nat.on_device(X.device):
         nat.check(nat.lib().gnx_gather_rows(nat.ptr(X), X.stride(0), nat.ptr(idx), idx.numel(), X.shape[1], nat.ptr(out),
                                             out.stride(0), nat.current_stream()))
     return out
@@ -446,7 +446,7 @@ def _dense_launch(X, W, bias, relu):
     b = None if bias is None else bias.to(torch.float32).reshape(-1).contiguous()
     if b is not None and b.numel() != W.shape[1]:
         raise Exception("dense: bias width mismatch")
-    with torch.cuda.device(X.device):
+    with nat.on_device(X.device):
         nat.check(nat.lib().gnx_dense(nat.ptr(X), X.stride(0), X.shape[0], X.shape[1], nat.ptr(W), W.stride(0), W.shape[1], nat.ptr(b),
                                       nat.ACT_RELU if relu else nat.ACT_NONE, nat.ptr(out), out.stride(0), nat.current_stream()))
     return out
@@ -497,14 +497,35 @@ def gcnii_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a: float, M: t
         raise Exception("gcnii_step: add_eye adjacencies are not supported by the fused step")
     out = torch.empty_like(H)
     work = None if C in (16, 32, 64) else torch.empty_like(H)
-    with torch.cuda.device(H.device):
+    with nat.on_device(H.device):
         nat.check(nat.lib().gnx_gcnii_step(g.handle, nat.ptr(adj.vals), nat.ptr(H), nat.ptr(H0), float(a), C, nat.ptr(M), M.stride(0),
                                            nat.ACT_RELU if relu else nat.ACT_NONE, nat.ptr(out), nat.ptr(work), nat.current_stream()))
     return out
 
 
-def _index64(x, device):
-    return torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x, dtype=torch.int64).to(device).contiguous()
+class DeviceIndex:
+    """Node ids / labels / edges of a task, checked ONCE on the host (range) and kept on the device: a task evaluates the same
+    index lists every epoch, and on small graphs an upload + a device-side check per call would dominate the epoch.
+    The kernels themselves never dereference an out-of-range id (NaN / -1 instead); device tensors handed in directly skip the
+    host check."""
+
+    def __init__(self, values, device, upper=None, what="node id"):
+        if isinstance(values, torch.Tensor):
+            self.tensor = values.to(device=device, dtype=torch.int64).contiguous()
+        else:
+            host = np.ascontiguousarray(np.asarray(values, dtype=np.int64))
+            if upper is not None and host.size and (int(host.min()) < 0 or int(host.max()) >= upper):
+                raise Exception(f"{what} out of range [0, {upper})")
+            self.tensor = torch.from_numpy(host).to(device)
+        self.upper = upper
+
+
+def _as_index(x, device, upper, what):
+    if isinstance(x, DeviceIndex):
+        if x.tensor.device != device or (x.upper is not None and upper is not None and x.upper != upper):
+            raise Exception("DeviceIndex built for another device / size")
+        return x.tensor
+    return DeviceIndex(x, device, upper, what).tensor
 
 
 class _NodeCE(torch.autograd.Function):
@@ -514,9 +535,9 @@ class _NodeCE(torch.autograd.Function):
     def forward(ctx, logits, nodes, labels):
         logits = _as_f32_rows(logits)
         m = nodes.numel()
-        per_node = torch.empty(m, dtype=torch.float32, device=logits.device)
+        per_node = torch.empty(m + 256, dtype=torch.float32, device=logits.device)       # + scratch of the two-level mean
         mean = torch.empty(1, dtype=torch.float32, device=logits.device)
-        with torch.cuda.device(logits.device):
+        with nat.on_device(logits.device):
             nat.check(nat.lib().gnx_node_ce(nat.ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], nat.ptr(nodes),
                                             nat.ptr(labels), m, nat.ptr(per_node), nat.ptr(mean), nat.current_stream()))
         ctx.save_for_backward(logits, nodes, labels)
@@ -527,16 +548,19 @@ class _NodeCE(torch.autograd.Function):
         logits, nodes, labels = ctx.saved_tensors
         grad = torch.zeros((logits.shape[0], logits.shape[1]), dtype=torch.float32, device=logits.device)
         g = g.to(torch.float32).reshape(1).contiguous()
-        with torch.cuda.device(logits.device):
-            nat.check(nat.lib().gnx_node_ce_backward(nat.ptr(logits), logits.stride(0), logits.shape[1], nat.ptr(nodes), nat.ptr(labels),
-                                                     nodes.numel(), nat.ptr(g), nat.ptr(grad), grad.stride(0), nat.current_stream()))
+        with nat.on_device(logits.device):
+            nat.check(nat.lib().gnx_node_ce_backward(nat.ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], nat.ptr(nodes),
+                                                     nat.ptr(labels), nodes.numel(), nat.ptr(g), nat.ptr(grad), grad.stride(0),
+                                                     nat.current_stream()))
         return grad, None, None
 
 
 def node_ce(logits: torch.Tensor, nodes, labels) -> torch.Tensor:
-    """The NodeClassification loss on the device in two small launches (gather + log-softmax + CE, then the mean)."""
+    """The NodeClassification loss on the device in two small launches (gather + log-softmax + CE, then the mean).
+    ``nodes`` / ``labels``: host sequences (range-checked here), DeviceIndex objects (checked when built) or device tensors."""
     nat.require_cuda(logits)
-    nodes, labels = _index64(nodes, logits.device), _index64(labels, logits.device)
+    nodes = _as_index(nodes, logits.device, logits.shape[0], "node id")
+    labels = _as_index(labels, logits.device, logits.shape[1], "label")
     if nodes.numel() != labels.numel() or nodes.numel() == 0:
         raise Exception("node_ce: nodes and labels must be equally long and non-empty")
     return _NodeCE.apply(logits, nodes, labels)
@@ -546,10 +570,10 @@ def node_argmax(logits: torch.Tensor, nodes=None) -> torch.Tensor:
     """argmax over the rows of ``nodes`` (all rows when None) in one launch; ties go to the lowest class."""
     nat.require_cuda(logits)
     logits = _as_f32_rows(logits.detach())
-    idx = None if nodes is None else _index64(nodes, logits.device)
+    idx = None if nodes is None else _as_index(nodes, logits.device, logits.shape[0], "node id")
     m = logits.shape[0] if idx is None else idx.numel()
     out = torch.empty(m, dtype=torch.int64, device=logits.device)
-    with torch.cuda.device(logits.device):
+    with nat.on_device(logits.device):
         nat.check(nat.lib().gnx_node_argmax(nat.ptr(logits), logits.stride(0), logits.shape[0], logits.shape[1], nat.ptr(idx), m,
                                             nat.ptr(out), nat.current_stream()))
     return out
@@ -618,7 +642,7 @@ class _EdgeScores(torch.autograd.Function):
         F = _as_f32_rows(F)
         rr = None if r is None else r.to(torch.float32).reshape(-1).contiguous()
         out = torch.empty(edges.shape[0], dtype=torch.float32, device=F.device)
-        with torch.cuda.device(F.device):
+        with nat.on_device(F.device):
             nat.check(nat.lib().gnx_edge_scores(nat.ptr(F), F.stride(0), F.shape[0], F.shape[1], nat.ptr(edges), edges.shape[0], nat.ptr(rr),
                                                 nat.ptr(out), nat.current_stream()))
         ctx.save_for_backward(F, edges, rr)
@@ -632,8 +656,8 @@ class _EdgeScores(torch.autograd.Function):
         gF = gr = None
         if ctx.needs_input_grad[0]:
             gF = torch.zeros((F.shape[0], F.shape[1]), dtype=torch.float32, device=F.device)
-            with torch.cuda.device(F.device):
-                nat.check(nat.lib().gnx_edge_scores_backward(nat.ptr(F), F.stride(0), F.shape[1], nat.ptr(edges), edges.shape[0], nat.ptr(rr),
+            with nat.on_device(F.device):
+                nat.check(nat.lib().gnx_edge_scores_backward(nat.ptr(F), F.stride(0), F.shape[0], F.shape[1], nat.ptr(edges), edges.shape[0], nat.ptr(rr),
                                                              nat.ptr(g), nat.ptr(gF), gF.stride(0), nat.current_stream()))
         if rr is not None and ctx.needs_input_grad[2]:
             gr = (g[:, None] * F[edges[:, 0]] * F[edges[:, 1]]).sum(0).reshape(ctx.r_shape)
@@ -643,5 +667,5 @@ class _EdgeScores(torch.autograd.Function):
 def edge_scores(F: torch.Tensor, edges, r=None) -> torch.Tensor:
     """Logits of the listed edges ([m, 2] node ids): <F[u], F[v]> or, with DistMult weights r [C, 1], <F[u] * F[v], r>."""
     nat.require_cuda(F, r)
-    e = torch.as_tensor(np.asarray(edges) if not isinstance(edges, torch.Tensor) else edges, dtype=torch.int64).reshape(-1, 2).to(F.device).contiguous()
+    e = _as_index(edges, F.device, F.shape[0], "edge endpoint").reshape(-1, 2)
     return _EdgeScores.apply(F, e, r)

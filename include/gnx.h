@@ -203,17 +203,20 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
 int gnx_dense(const float *d_X, int64_t ldx, int64_t n, int64_t F, const float *d_W, int64_t ldw, int64_t O,
               const float *d_bias, int act, float *d_out, int64_t ldo, void *stream);
 
-/* The task head, NodeClassification (gnntf/core/gnn/graph_predictor.py:16-31), fused over the listed nodes:
+/* The task head, NodeClassification (gnntf/core/gnn/graph_predictor.py:16-31), fused over the listed nodes.  All three are
+ * stream-ordered and allocation-free (no synchronisation: they sit in the per-epoch loop of small graphs); node ids / labels
+ * out of range are never dereferenced -- such an item's loss is NaN (and so is the mean), its argmax -1, its gradient zero.
  * gnx_node_ce:      d_loss_per_node[i] = logsumexp(logits[nodes[i], :]) - logits[nodes[i], labels[i]] and their mean in
  *                   d_mean_loss[0] (= SparseCategoricalCrossentropy(from_logits) of log_softmax, graph_predictor.py:24-25).
- *                   Synchronises the stream (reports out-of-range node ids / labels as GNX_ERR_INVALID).
+ *                   d_loss_per_node must hold m + 256 floats (the tail is scratch of the fixed-order two-level mean).
  * gnx_node_ce_backward: d_grad_logits[nodes[i], :] += d_grad_loss[0] / m * (softmax(logits[nodes[i], :]) - onehot(labels[i]));
  *                   the caller zero-fills d_grad_logits [n_rows, C] first.
  * gnx_node_argmax:  d_out[i] = first index of the maximum of logits[nodes[i], :] (d_nodes NULL: row i); graph_predictor.py:17. */
 int gnx_node_ce(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes,
                 const int64_t *d_labels, int64_t m, float *d_loss_per_node, float *d_mean_loss, void *stream);
-int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t C, const int64_t *d_nodes, const int64_t *d_labels,
-                         int64_t m, const float *d_grad_loss, float *d_grad_logits, int64_t ldg, void *stream);
+int gnx_node_ce_backward(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes,
+                         const int64_t *d_labels, int64_t m, const float *d_grad_loss, float *d_grad_logits, int64_t ldg,
+                         void *stream);
 int gnx_node_argmax(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, int64_t m,
                     int64_t *d_out, void *stream);
 
@@ -243,12 +246,13 @@ int gnx_halo_exchange(gnx_halo_plan_t plan, void *nccl_comm, const float *d_send
 
 /* The link head, LinkPrediction.predict / loss (gnntf/core/gnn/graph_predictor.py:122-126, 136-144): the logit of every listed
  * edge, d_out[i] = sum_c F[u_i, c] * F[v_i, c] * (d_r[c] or 1) -- gather of both endpoint rows + product + (DistMult) weights
- * + reduction in one launch; d_edges int64 [m, 2].  Synchronises the stream (out-of-range endpoints -> GNX_ERR_INVALID).
+ * + reduction in one launch; d_edges int64 [m, 2].  Stream-ordered, allocation-free; an edge with an endpoint out of range
+ * gets NaN (nothing is dereferenced) and no gradient.
  * gnx_edge_scores_backward: d_grad_F[u_i, :] += g_i * F[v_i, :] * r and the mirror for v_i (caller zero-fills d_grad_F). */
 int gnx_edge_scores(const float *d_F, int64_t ldf, int64_t n_rows, int64_t C, const int64_t *d_edges, int64_t m,
                     const float *d_r, float *d_out, void *stream);
-int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t C, const int64_t *d_edges, int64_t m, const float *d_r,
-                             const float *d_grad_out, float *d_grad_F, int64_t ldg, void *stream);
+int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t n_rows, int64_t C, const int64_t *d_edges, int64_t m,
+                             const float *d_r, const float *d_grad_out, float *d_grad_F, int64_t ldg, void *stream);
 
 /* Halo packing for the vertex-partitioned path: out[r,:] = X[idx[r],:], idx int64 [n_idx]. */
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,

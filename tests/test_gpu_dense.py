@@ -134,6 +134,13 @@ def test_node_head(gnntf):
         gnntf.node_ce(dev(logits), [0, 1], [0, 129])
     with pytest.raises(Exception, match="out of range"):
         gnntf.node_argmax(dev(logits), [-1])
+    # ids handed over as DEVICE tensors skip the host check: the kernels never dereference them -- NaN loss, -1 argmax, no gradient
+    bad_nodes = torch.tensor([0, n, 5], device="cuda"); some_labels = torch.tensor([0, 0, 0], device="cuda")
+    Lb = dev(logits).requires_grad_()
+    bad = gnntf.node_ce(Lb, bad_nodes, some_labels)
+    assert bool(torch.isnan(bad))
+    assert gnntf.node_argmax(dev(logits), bad_nodes).cpu().numpy().tolist() == [int(logits[0].argmax()), -1, int(logits[5].argmax())]
+    assert bool(torch.isnan(gnntf.edge_scores(dev(logits), torch.tensor([[0, 1], [2, n]], device="cuda"))[1]))
     # through the task API (graph_predictor.py:10-31)
     task = gnntf.NodeClassification(list(range(50)), labels[:50] % 7)
     small = dev(logits[:, :7].copy())
