@@ -25,7 +25,10 @@ def dev(x):
 
 
 @pytest.mark.parametrize("n,F,O", [(1, 1, 1), (100, 7, 3), (1000, 128, 64), (513, 1433, 64), (300, 64, 40), (2049, 64, 7), (257, 100, 300),
-                                   (64, 16, 16), (130, 257, 129), (4097, 512, 256)])
+                                   (64, 16, 16), (130, 257, 129), (4097, 512, 256),
+                                   # tall enough for the W-resident persistent kernel (n >= 4096, F <= 256 and W within LDS)
+                                   (5000, 64, 40), (4100, 128, 64), (9001, 256, 64), (4097, 200, 33), (6000, 128, 128), (5000, 60, 256),
+                                   (300001, 100, 7)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_dense_mfma_matches_float64(gnntf, n, F, O, relu):
     rng = np.random.default_rng(n + F + O)
