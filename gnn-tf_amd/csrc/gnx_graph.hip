@@ -168,6 +168,20 @@ __global__ void k_make_tkeys(const int32_t *__restrict__ rowidx, const int32_t *
     payload[k] = (int32_t)k;
 }
 
+// relabelling (vertex row_order[i] -> i): newid = inverse of row_order; key of an entry = newid[row] * n + newid[col]
+__global__ void k_invert_order(const int32_t *__restrict__ order, int64_t n, int32_t *__restrict__ newid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) newid[order[i]] = (int32_t)i;
+}
+
+__global__ void k_make_rkeys(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ colidx, const int32_t *__restrict__ newid,
+                             int64_t nnz, int64_t n, uint64_t *__restrict__ keys, int32_t *__restrict__ payload) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    keys[k] = (uint64_t)newid[rowidx[k]] * (uint64_t)n + (uint64_t)newid[colidx[k]];
+    payload[k] = (int32_t)k;
+}
+
 __global__ void k_permute_vals(const float *__restrict__ vals, const int32_t *__restrict__ perm, int64_t n,
                                float *__restrict__ out) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,6 +340,58 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
     return GNX_OK;
 }
 
+static void drop_relabel(gnx_graph *g) {
+    free_csr(g->r);
+    if (g->r_perm) (void)hipFree(g->r_perm);
+    if (g->r_vals) (void)hipFree(g->r_vals);
+    g->r_perm = nullptr; g->r_vals = nullptr;
+    g->has_r = false;
+}
+
+int ensure_relabel_features(gnx_graph *g, size_t bytes) {
+    if (bytes <= g->r_feat_bytes) return GNX_OK;
+    if (g->r_feat) (void)hipFree(g->r_feat);
+    g->r_feat = nullptr; g->r_feat_bytes = 0;
+    GNX_HIP(hipMalloc((void **)&g->r_feat, bytes));
+    g->r_feat_bytes = bytes;
+    return GNX_OK;
+}
+
+// The matrix with its vertices renumbered in the degree-binned order (heaviest first): same entries, rows and columns permuted
+// alike, columns ascending inside a row.  Built once, on the first narrow-width propagation of a large square graph.
+int ensure_relabel(gnx_graph *g, hipStream_t s) {
+    if (g->has_r) return GNX_OK;
+    struct Undo { gnx_graph *g; ~Undo() { if (g && !g->has_r) drop_relabel(g); } } undo{g};
+    const Csr &a = g->a;
+    Csr &r = g->r;
+    GNX_CHECK_ARG(a.n_rows == a.n_cols && a.row_order != nullptr && a.nnz > 0, "relabelling needs a non-empty square graph");
+    const int64_t n = a.n_rows, nnz = a.nnz;
+    r.n_rows = n; r.n_cols = n; r.nnz = nnz;
+    GNX_HIP(hipMalloc((void **)&r.rowptr, (n + 1) * sizeof(int64_t)));
+    GNX_HIP(hipMalloc((void **)&r.colidx, nnz * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&g->r_perm, nnz * sizeof(int32_t)));
+    GNX_HIP(hipMalloc((void **)&g->r_vals, nnz * sizeof(float)));
+    DevBuf newid, k0, k1, p0, rrow, tmp;
+    GNX_HIP(newid.alloc(n * 4)); GNX_HIP(k0.alloc(nnz * 8)); GNX_HIP(k1.alloc(nnz * 8)); GNX_HIP(p0.alloc(nnz * 4)); GNX_HIP(rrow.alloc(nnz * 4));
+    hipLaunchKernelGGL(k_invert_order, dim3(blocks_for(n)), dim3(256), 0, s, a.row_order, n, newid.as<int32_t>());
+    hipLaunchKernelGGL(k_make_rkeys, dim3(blocks_for(nnz)), dim3(256), 0, s, g->rowidx, a.colidx, newid.as<int32_t>(), nnz, n,
+                       k0.as<uint64_t>(), p0.as<int32_t>());
+    const unsigned end_bit = bits_for((uint64_t)n * (uint64_t)n);
+    size_t tb = 0;
+    GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<int32_t>(), g->r_perm, (size_t)nnz, 0u,
+                                      end_bit, s));
+    GNX_HIP(tmp.alloc(tb));
+    GNX_HIP(rocprim::radix_sort_pairs(tmp.p, tb, k0.as<uint64_t>(), k1.as<uint64_t>(), p0.as<int32_t>(), g->r_perm, (size_t)nnz, 0u,
+                                      end_bit, s));
+    hipLaunchKernelGGL(k_split_tkeys, dim3(blocks_for(nnz)), dim3(256), 0, s, k1.as<uint64_t>(), nnz, n, rrow.as<int32_t>(), r.colidx);
+    hipLaunchKernelGGL(k_lower_bound_rows, dim3(blocks_for(n + 1)), dim3(256), 0, s, rrow.as<int32_t>(), nnz, n, r.rowptr);
+    GNX_HIP(hipStreamSynchronize(s));
+    int rc = build_long_plan(r, s);
+    if (rc != GNX_OK) return rc;
+    g->has_r = true;
+    return GNX_OK;
+}
+
 static int finish_graph(gnx_graph *g, hipStream_t s) {
     int rc = build_long_plan(g->a, s);
     if (rc != GNX_OK) return rc;
@@ -356,6 +422,10 @@ int gnx_graph_destroy(gnx_graph_t g) {
     if (g->t_rowidx) (void)hipFree(g->t_rowidx);
     if (g->partial) (void)hipFree(g->partial);
     if (g->deg) (void)hipFree(g->deg);
+    free_csr(g->r);
+    if (g->r_perm) (void)hipFree(g->r_perm);
+    if (g->r_vals) (void)hipFree(g->r_vals);
+    if (g->r_feat) (void)hipFree(g->r_feat);
     delete g;
     return GNX_OK;
 }

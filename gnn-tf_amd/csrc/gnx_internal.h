@@ -81,6 +81,14 @@ struct gnx_graph {
     float *partial = nullptr;
     size_t partial_bytes = 0;
     float *deg = nullptr;        // [a.n_cols] scratch for column sums / degree scales (lazy)
+    // degree-relabelled copy of a square matrix (lazy; narrow feature widths): vertex a.row_order[i] becomes vertex i, so the
+    // rows of the hubs -- which most gathers hit -- are neighbours in memory and share cache lines
+    bool has_r = false;
+    gnx::Csr r;
+    int32_t *r_perm = nullptr;   // [a.nnz] coalesced slot of every relabelled entry
+    float *r_vals = nullptr;     // [a.nnz] scratch: values gathered into relabelled order
+    float *r_feat = nullptr;     // scratch: H0 in relabelled row order
+    size_t r_feat_bytes = 0;
     const char *last_kernel = "";
 };
 
@@ -90,6 +98,8 @@ int build_long_plan(Csr &m, hipStream_t s);
 void free_csr(Csr &m);
 int ensure_transpose(gnx_graph *g, hipStream_t s);
 int ensure_partial(gnx_graph *g, size_t bytes);
+int ensure_relabel(gnx_graph *g, hipStream_t s);
+int ensure_relabel_features(gnx_graph *g, size_t bytes);
 
 // ---- counter RNG of the edge dropout: the same integer arithmetic as oracle/gnntf_oracle.py:hash_u24 ----------
 __device__ __forceinline__ uint64_t rng_fin(uint64_t z) {

@@ -204,6 +204,33 @@ def test_k_loop_skips_settled_empty_rows_bitwise(gnntf):
     assert torch.equal(gnntf.appnp_propagate(eye, H0, a=0.2, iterations=5), H)
 
 
+def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
+    """gnx_appnp_propagate at C <= 16 on a large graph runs on the degree-relabelled copy of the matrix (H0 permuted in, the last
+    iteration scattered back): same result as K plain steps up to float32 rounding (the columns of a row are summed in another
+    order), for every K parity, unaligned widths, weighted directed patterns and empty rows; C > 16 keeps the plain path bitwise."""
+    n = 1_200_000
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rows = (torch.rand(6_000_000, device="cuda", generator=gen) ** 3 * (n * 0.7)).long()          # skewed; rows above 0.7 n stay empty
+    cols = (torch.rand(6_000_000, device="cuda", generator=gen) ** 2 * n).long().clamp_(max=n - 1)
+    idx = torch.unique(torch.stack([rows, cols], 1), dim=0)
+    vals = torch.rand(idx.shape[0], device="cuda", generator=gen) + 0.5
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, vals, (n, n)), device="cuda:0")
+    adj = gnntf.normalize(g, "symmetric")
+    for C in (7, 8, 16, 24):
+        H0 = torch.rand(n, C, device="cuda", generator=gen) * 2 - 1
+        for K in (1, 2, 3, 10):
+            H = H0
+            for _ in range(K):
+                H = gnntf.ppr_step(adj, H, H0, 0.15)
+            got = gnntf.appnp_propagate(adj, H0, a=0.15, iterations=K)
+            if C > 16:
+                assert torch.equal(got, H)
+            else:
+                assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
+                assert torch.equal(got[int(n * 0.75):], H[int(n * 0.75):])           # rows without entries: exactly a * H0
+    del g, adj
+
+
 def test_hand_graphs(gnntf):
     """KAT-2 on the device: isolated nodes -> a*H0; doubled COO == single COO; directed column-sum rule."""
     idx, vals, shape = orc.graph2adj(range(8), [(0, i) for i in range(1, 6)])
