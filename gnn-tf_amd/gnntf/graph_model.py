@@ -136,6 +136,15 @@ class PPRLoop(Layer):
                 # the degree scales of all K iterations in one pass over the structure; kept (K x N floats) for the backward
                 scales = sparse.dropped_degree_scales(graph, p, seed, first, self.iterations)
                 make_adj = lambda k, bwd=False: sparse.dropped_adjacency(graph, p, seed, first + k, D=scales[k])
+            elif graph.nnz * self.iterations * 4 <= (64 << 20):
+                # small graph (launch-latency regime): keep the K materialised adjacencies for the backward (one permute launch
+                # there instead of three launches to regenerate); large graphs regenerate to save K nnz-sized arrays
+                kept = dict()
+
+                def make_adj(k, bwd=False):
+                    if k not in kept:
+                        kept[k] = sparse.normalize(graph, "symmetric", "none", p, seed, first + k)
+                    return kept.pop(k) if bwd else kept[k]
             else:
                 make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
         else:
