@@ -30,6 +30,7 @@ struct DenseArgs {
     float *out; int64_t ldo;
     const int32_t *out_rows;      // optional: result row r goes to out[out_rows[r]]
     const int32_t *in_rows;       // optional: input row r is X[in_rows[r]]
+    bool w_aligned;               // W rows start 16-byte aligned (ldw % 4 == 0, aligned base): float4 loads of W
 };
 
 template <int NT> struct DenseCfg {
@@ -38,14 +39,16 @@ template <int NT> struct DenseCfg {
     static constexpr int STRIDE = OP + 4;              // OP is a multiple of 16; +4 makes row stride = 4 (mod 8): see header
 };
 
+constexpr int DENSE_WAVES = 8;       // waves (16-row strips) per block: 128 rows share one W chunk in LDS
+
 template <int NT, bool ALIGNED>
-__global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
+__global__ __launch_bounds__(64 * DENSE_WAVES) void k_dense_mfma(const DenseArgs p) {
     using Cfg = DenseCfg<NT>;
     __shared__ float Ws[Cfg::KC * Cfg::STRIDE];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    const int64_t row0 = (int64_t)blockIdx.x * (16 * DENSE_WAVES) + wave * 16;
     int64_t arow = row0 + c < p.n ? row0 + c : p.n - 1;                  // rows past the end read a valid row and are not stored
     if (p.in_rows) arow = p.in_rows[arow];
     const float *__restrict__ xrow = p.X + arow * p.ldx;
@@ -70,10 +73,19 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
     load_a(0, a);
     for (int k0 = 0; k0 < p.F; k0 += Cfg::KC) {
         __syncthreads();                                                   // the previous chunk has been consumed
-        for (int idx = threadIdx.x; idx < Cfg::KC * Cfg::OP; idx += 256) {
-            const int r = idx / Cfg::OP, cc = idx % Cfg::OP;
+        for (int idx = threadIdx.x; idx < Cfg::KC * (Cfg::OP / 4); idx += 64 * DENSE_WAVES) {      // 16 bytes of W per thread and step
+            const int r = idx / (Cfg::OP / 4), cc = (idx % (Cfg::OP / 4)) * 4;
             const int k = k0 + r;
-            Ws[r * Cfg::STRIDE + cc] = (k < p.F && cc < p.O) ? p.W[(int64_t)k * p.ldw + cc] : 0.f;
+            f32x4 w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < p.F) {
+                const float *__restrict__ wr = p.W + (int64_t)k * p.ldw + cc;
+                if (p.w_aligned && cc + 3 < p.O) w = *reinterpret_cast<const f32x4 *>(wr);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (cc + t < p.O) w[t] = wr[t];
+                }
+            }
+            *reinterpret_cast<f32x4 *>(Ws + r * Cfg::STRIDE + cc) = w;
         }
         if (k0 + Cfg::KC < p.F) load_a(k0 + Cfg::KC, a_next);              // the next chunk's rows are in flight under this chunk's MFMAs
         __syncthreads();
@@ -112,9 +124,9 @@ __global__ __launch_bounds__(256) void k_dense_mfma(const DenseArgs p) {
 
 template <int NT>
 void launch_dense(const DenseArgs &p, bool aligned, hipStream_t s) {
-    const unsigned grid = (unsigned)((p.n + 63) / 64);
-    if (aligned) hipLaunchKernelGGL((k_dense_mfma<NT, true>), dim3(grid), dim3(256), 0, s, p);
-    else         hipLaunchKernelGGL((k_dense_mfma<NT, false>), dim3(grid), dim3(256), 0, s, p);
+    const unsigned grid = (unsigned)((p.n + 16 * DENSE_WAVES - 1) / (16 * DENSE_WAVES));
+    if (aligned) hipLaunchKernelGGL((k_dense_mfma<NT, true>), dim3(grid), dim3(64 * DENSE_WAVES), 0, s, p);
+    else         hipLaunchKernelGGL((k_dense_mfma<NT, false>), dim3(grid), dim3(64 * DENSE_WAVES), 0, s, p);
 }
 
 // ---- task head -----------------------------------------------------------------------------------------------------------
@@ -280,11 +292,12 @@ namespace gnx {
 int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W, int64_t ldw, int64_t O, const float *bias, int act,
                const int32_t *in_rows, const int32_t *out_rows, float *out, int64_t ldo, hipStream_t s) {
     if (n == 0) return GNX_OK;
-    DenseArgs p{X, ldx, n, (int)F, W, ldw, (int)O, bias, act, out, ldo, out_rows, in_rows};
+    DenseArgs p{X, ldx, n, (int)F, W, ldw, (int)O, bias, act, out, ldo, out_rows, in_rows, false};
     const bool al = ldx % 4 == 0 && aligned16(X);
     for (int64_t o0 = 0; o0 < O; o0 += 256) {                         // column panels of at most 256 outputs
         DenseArgs q = p;
         q.W = W + o0; q.bias = bias ? bias + o0 : nullptr; q.out = out + o0;
+        q.w_aligned = ldw % 4 == 0 && aligned16(q.W);
         q.O = (int)(O - o0 < 256 ? O - o0 : 256);
         const int nt = (q.O + 15) / 16;
         if (nt <= 1) launch_dense<1>(q, al, s);
