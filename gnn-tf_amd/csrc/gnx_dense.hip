@@ -129,6 +129,97 @@ void launch_dense(const DenseArgs &p, bool aligned, hipStream_t s) {
     else         hipLaunchKernelGGL((k_dense_mfma<NT, false>), dim3(grid), dim3(64 * DENSE_WAVES), 0, s, p);
 }
 
+// ---- weight gradient of the dense layer: dW[F, O] = X^T . G, a reduction over the N rows ------------------------------------
+// M = F, N = O, K = rows.  grid.x = row slabs, grid.y = panels of 256 features, grid.z = panels of 16 NT outputs.  A block
+// stages 32-row tiles of X (its 256 features) and G (its outputs) in LDS with coalesced 16-byte loads; wave w owns features
+// [64 w, 64 w + 64) of the panel as 4 x NT accumulator tiles: A[m = feature][k = row] and B[k = row][n = output] fragments are
+// read from LDS (row stride = 16 mod 32 banks, so the two k-groups of a half-wave hit disjoint banks).  Every slab writes its
+// partial dW; a second kernel adds the slabs in order (fixed order: reproducible, no float atomics).
+template <int NT>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ X, int64_t ldx, const float *__restrict__ G, int64_t ldg,
+                                                     int64_t n, int F, int O, int64_t rows_per_slab, bool aligned,
+                                                     float *__restrict__ partial) {
+    constexpr int R = 32, XS = 256 + 16, GS = 16 * NT + 16;
+    __shared__ float Xs[R * XS];
+    __shared__ float Gs[R * GS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int f0 = blockIdx.y * 256, o0 = blockIdx.z * 16 * NT;
+    const int64_t r_beg = (int64_t)blockIdx.x * rows_per_slab;
+    const int64_t r_end = r_beg + rows_per_slab < n ? r_beg + rows_per_slab : n;
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t r0 = r_beg; r0 < r_end; r0 += R) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < R * 64; idx += 256) {                 // X tile: 32 rows x 256 features
+            const int rr = idx / 64, cc = (idx % 64) * 4;
+            const int64_t row = r0 + rr;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < r_end) {
+                const float *__restrict__ src = X + row * ldx + f0 + cc;
+                if (aligned && f0 + cc + 3 < F) v = *reinterpret_cast<const f32x4 *>(src);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (f0 + cc + t < F) v[t] = src[t];
+                }
+            }
+            *reinterpret_cast<f32x4 *>(Xs + rr * XS + cc) = v;
+        }
+        for (int idx = threadIdx.x; idx < R * 4 * NT; idx += 256) {             // G tile: 32 rows x 16 NT outputs
+            const int rr = idx / (4 * NT), cc = (idx % (4 * NT)) * 4;
+            const int64_t row = r0 + rr;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < r_end) {
+                const float *__restrict__ src = G + row * ldg + o0 + cc;
+                if (aligned && o0 + cc + 3 < O) v = *reinterpret_cast<const f32x4 *>(src);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (o0 + cc + t < O) v[t] = src[t];
+                }
+            }
+            *reinterpret_cast<f32x4 *>(Gs + rr * GS + cc) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < R / 4; ++kk) {
+            const float *__restrict__ xrow = Xs + (4 * kk + g) * XS + 64 * wave + c;
+            const float *__restrict__ grow = Gs + (4 * kk + g) * GS + c;
+            float b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = grow[16 * nt];
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const float a = xrow[16 * ft];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[ft][nt], 0, 0, 0);
+            }
+        }
+    }
+    float *__restrict__ out = partial + (int64_t)blockIdx.x * F * O;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int o = o0 + 16 * nt + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = f0 + 64 * wave + 16 * ft + 4 * g + r;
+                if (f < F && o < O) out[(int64_t)f * O + o] = acc[ft][nt][r];
+            }
+        }
+}
+
+__global__ void k_sum_slabs(const float *__restrict__ partial, int64_t n_slabs, int64_t elems, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    float acc = 0.f;
+    for (int64_t s = 0; s < n_slabs; ++s) acc += partial[s * elems + e];      // slab order
+    out[e] = acc;
+}
+
 // ---- task head -----------------------------------------------------------------------------------------------------------
 // One 16-lane group per listed node: gather the row, max, sum of exponentials, loss_i = logsumexp - x[label]
 // (graph_predictor.py:24-25: CE-from-logits applied to log_softmax(x); softmax(log_softmax(x)) = softmax(x), so this IS the
@@ -327,6 +418,38 @@ int gnx_dense(const float *d_X, int64_t ldx, int64_t n, int64_t F, const float *
     GNX_CHECK_ARG(d_X && d_W && d_out, "gnx_dense: NULL pointer");
     GNX_CHECK_ARG((const void *)d_X != (const void *)d_out, "gnx_dense: out must not alias X");
     return dense_rows(d_X, ldx, n, F, d_W, ldw, O, d_bias, act, nullptr, nullptr, d_out, ldo, (hipStream_t)stream);
+}
+
+int gnx_dense_wgrad(const float *d_X, int64_t ldx, const float *d_G, int64_t ldg, int64_t n, int64_t F, int64_t O, float *d_dW,
+                    float *d_work, int64_t work_floats, void *stream) {
+    GNX_CHECK_ARG(n >= 0 && F >= 1 && O >= 1 && F <= (1 << 20) && O <= (1 << 20), "gnx_dense_wgrad: bad sizes");
+    GNX_CHECK_ARG(ldx >= F && ldg >= O, "gnx_dense_wgrad: leading dimension smaller than the row");
+    GNX_CHECK_ARG(d_dW != nullptr, "gnx_dense_wgrad: NULL output");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        GNX_HIP(hipMemsetAsync(d_dW, 0, (size_t)F * O * sizeof(float), s));
+        return GNX_OK;
+    }
+    GNX_CHECK_ARG(d_X && d_G, "gnx_dense_wgrad: NULL input");
+    // row slabs: as many as the scratch holds (each slab leaves an F x O partial), at least 256 rows each, at most 2048 slabs
+    const int64_t fo = F * O;
+    int64_t max_slabs = work_floats / fo;
+    GNX_CHECK_ARG(d_work != nullptr && max_slabs >= 1, "gnx_dense_wgrad: the scratch must hold at least F * O floats");
+    if (max_slabs > 2048) max_slabs = 2048;
+    int64_t rows_per_slab = (n + max_slabs - 1) / max_slabs;
+    if (rows_per_slab < 256) rows_per_slab = 256;
+    rows_per_slab = (rows_per_slab + 31) / 32 * 32;
+    const int64_t n_slabs = (n + rows_per_slab - 1) / rows_per_slab;
+    const bool al = ldx % 4 == 0 && ldg % 4 == 0 && aligned16(d_X) && aligned16(d_G);
+    const int nt_all = (int)((O + 15) / 16);
+    const int NTsel = nt_all >= 4 ? 4 : (nt_all >= 2 ? 2 : 1);
+    dim3 grid((unsigned)n_slabs, (unsigned)((F + 255) / 256), (unsigned)((nt_all + NTsel - 1) / NTsel));
+    if (NTsel == 4)      hipLaunchKernelGGL(k_wgrad_mfma<4>, grid, dim3(256), 0, s, d_X, ldx, d_G, ldg, n, (int)F, (int)O, rows_per_slab, al, d_work);
+    else if (NTsel == 2) hipLaunchKernelGGL(k_wgrad_mfma<2>, grid, dim3(256), 0, s, d_X, ldx, d_G, ldg, n, (int)F, (int)O, rows_per_slab, al, d_work);
+    else                 hipLaunchKernelGGL(k_wgrad_mfma<1>, grid, dim3(256), 0, s, d_X, ldx, d_G, ldg, n, (int)F, (int)O, rows_per_slab, al, d_work);
+    hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((fo + 255) / 256)), dim3(256), 0, s, d_work, n_slabs, fo, d_dW);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
 }
 
 int gnx_node_ce(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t C, const int64_t *d_nodes, const int64_t *d_labels, int64_t m,

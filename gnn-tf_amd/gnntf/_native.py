@@ -58,6 +58,7 @@ SIGNATURES = {
                                c_void_p, c_void_p]),
     "gnx_dense": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64,
                           c_void_p]),
+    "gnx_dense_wgrad": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_node_ce": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gnx_node_ce_backward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                      c_void_p]),

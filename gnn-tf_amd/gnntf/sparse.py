@@ -452,10 +452,24 @@ def _dense_launch(X, W, bias, relu):
     return out
 
 
+def _dense_wgrad(X, G):
+    """dW = X^T . G on the matrix cores (gnx_dense_wgrad): row slabs, partial sums added in a fixed order."""
+    X, G = _as_f32_rows(X), _as_f32_rows(G)
+    n, F = X.shape
+    O = G.shape[1]
+    slabs = max(1, min(2048, (n + 255) // 256, (1 << 28) // max(F * O, 1)))        # scratch capped at 1 GiB
+    work = torch.empty(slabs * F * O, dtype=torch.float32, device=X.device)
+    dW = torch.empty((F, O), dtype=torch.float32, device=X.device)
+    with nat.on_device(X.device):
+        nat.check(nat.lib().gnx_dense_wgrad(nat.ptr(X), X.stride(0), nat.ptr(G), G.stride(0), n, F, O, nat.ptr(dW), nat.ptr(work),
+                                            work.numel(), nat.current_stream()))
+    return dW
+
+
 class _DenseAct(torch.autograd.Function):
     """out = act(X . W + b) on the matrix cores (layers.py:135-136; the transform of gcn.py:89).
-    backward: g' = g * (out > 0); dX = g' . W^T through the same kernel; dW = X^T . g' and db = column sums of g' are
-    reductions over the N rows, left to the library GEMM / a torch reduction (they are not on the forward path)."""
+    backward: g' = g * (out > 0); dX = g' . W^T through the same kernel; dW = X^T . g' through gnx_dense_wgrad (MFMA over row
+    slabs); db = column sums of g' (a torch reduction)."""
 
     @staticmethod
     def forward(ctx, X, W, bias, relu):
@@ -471,7 +485,7 @@ class _DenseAct(torch.autograd.Function):
         g = (g * (out > 0)) if ctx.relu else g
         g = g.contiguous()
         gX = _dense_launch(g, W.t().contiguous(), None, False) if ctx.needs_input_grad[0] else None
-        gW = torch.matmul(X.t(), g) if ctx.needs_input_grad[1] else None
+        gW = _dense_wgrad(X, g) if ctx.needs_input_grad[1] else None
         gb = g.sum(dim=0).reshape(ctx.bias_shape) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gX, gW, gb, None
 

@@ -203,6 +203,13 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
 int gnx_dense(const float *d_X, int64_t ldx, int64_t n, int64_t F, const float *d_W, int64_t ldw, int64_t O,
               const float *d_bias, int act, float *d_out, int64_t ldo, void *stream);
 
+/* gnx_dense_wgrad: dW = X^T . G, the weight gradient of gnx_dense (what tf.GradientTape derives for layers.py:136,
+ * trainable.py:70-78): X [n, F], G [n, O] (the gradient of the pre-activation), dW [F, O] contiguous.  float32 MFMA over row
+ * slabs; d_work [work_floats] is scratch for the per-slab partial sums (>= F * O floats; more scratch = more slabs in flight,
+ * 2048 * F * O is the most it uses); the slabs are added in a fixed order (reproducible). */
+int gnx_dense_wgrad(const float *d_X, int64_t ldx, const float *d_G, int64_t ldg, int64_t n, int64_t F, int64_t O, float *d_dW,
+                    float *d_work, int64_t work_floats, void *stream);
+
 /* The task head, NodeClassification (gnntf/core/gnn/graph_predictor.py:16-31), fused over the listed nodes.  All three are
  * stream-ordered and allocation-free (no synchronisation: they sit in the per-epoch loop of small graphs); node ids / labels
  * out of range are never dereferenced -- such an item's loss is NaN (and so is the mean), its argmax -1, its gradient zero.

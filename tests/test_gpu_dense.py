@@ -72,6 +72,22 @@ def test_dense_backward(gnntf):
         np.testing.assert_allclose(a, w, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("n,F,O", [(1, 1, 1), (33, 5, 3), (1000, 96, 48), (5000, 256, 64), (4097, 300, 7), (2500, 1433, 64), (70000, 64, 40),
+                                   (3000, 128, 200)])
+def test_dense_weight_gradient_mfma(gnntf, n, F, O):
+    """gnx_dense_wgrad: dW = X^T . G over row slabs on the matrix cores, slabs added in a fixed order -- against float64, twice
+    (bitwise repeatable), with unaligned strided operands too."""
+    from gnntf.sparse import _dense_wgrad
+    rng = np.random.default_rng(n + F)
+    X, G = rng.standard_normal((n, F)).astype(np.float32), rng.standard_normal((n, O)).astype(np.float32)
+    got = _dense_wgrad(dev(X), dev(G))
+    want = X.astype(np.float64).T @ G.astype(np.float64)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=2e-4 * np.sqrt(n))
+    assert torch.equal(got, _dense_wgrad(dev(X), dev(G)))
+    big = dev(np.pad(X, ((0, 0), (3, 2))))                                      # ld F + 5, offset 3
+    np.testing.assert_allclose(_dense_wgrad(big[:, 3:3 + F], dev(G)).cpu().numpy(), want, rtol=RTOL, atol=2e-4 * np.sqrt(n))
+
+
 def hub_graph(n, m, hub_entries, seed):
     """An R-MAT graph plus one hub row/column with more than LONG_ROW (512) entries."""
     coo, vals, shape = graphs.rmat_symmetric_coo(n, m, seed=seed)
