@@ -113,6 +113,24 @@ def timed_steps(step, steps, warmup, barrier):
     return elapsed, [s.elapsed_time(e) for s, e in ev]
 
 
+def stream_read_GBs(device, nbytes=8 << 30, reps=5):
+    """Device read-only streaming rate measured in this run (the SpMM is almost all reads)."""
+    import torch
+    from gnntf import _native as nat
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
+    sink = torch.zeros(64, dtype=torch.float32, device=device)
+    read = lambda: nat.check(nat.lib().gnx_stream_read(nat.ptr(src), src.numel(), nat.ptr(sink), nat.current_stream()))
+    read()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        read()
+    e.record()
+    torch.cuda.synchronize()
+    return 1.0 * nbytes * reps / (s.elapsed_time(e) * 1e-3) / 1e9
+
+
 def stream_copy_GBs(device, nbytes=4 << 30, reps=5):
     """Device stream-copy rate (read + write bytes per second) measured in this run: the achievable HBM peak."""
     import torch
@@ -142,6 +160,9 @@ def pmc_traffic(name):
     return float(rec["fabric_bytes_per_launch"]), f"profiles/pmc_traffic.json [{rec.get('source', '')}] -- builder-run rocprofv3 --pmc passes of this command, NOT measured in this run"
 
 
+MEASURED_READ_PEAK = [None]        # in-run read-only streaming rate (set once by main)
+
+
 def roofline_record(n, nnz, C, launch_s, K, name, measured_peak):
     """achieved = min(B_alg, B_rocprof) / t per launch; B_alg, B_min, B_rocprof and t printed together."""
     b_alg, b_min = alg_bytes_per_iteration(n, nnz, C), min_bytes_per_iteration(n, nnz, C)
@@ -152,9 +173,12 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak):
            "traffic": traffic, "traffic_source": source, "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
            "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K, "alg_GBs": b_alg / launch_s / 1e9,
            "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if measured_peak else None,
+           "measured_read_peak": MEASURED_READ_PEAK[0],
+           "frac_of_measured_read_peak": (achieved / MEASURED_READ_PEAK[0]) if MEASURED_READ_PEAK[0] else None,
            "note": "one launch = one fused SpMM+mix iteration incl. its long-row kernels; achieved = min(B_alg, traffic) / launch time; "
                    "traffic = bytes leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE): Infinity-Cache hits are counted in it, so this is a "
-                   "fabric-level figure, not DRAM bandwidth; measured_peak = in-run device stream copy (read + write)"}
+                   "fabric-level figure, not DRAM bandwidth; measured_peak = in-run device stream copy (read + write), measured_read_peak = in-run "
+                   "read-only stream (the SpMM is almost all reads)"}
     return rec
 
 
@@ -406,6 +430,7 @@ def main():
     if rank == 0:
         edges = nnz_global * K * args.steps
         measured_peak = stream_copy_GBs(device)
+        MEASURED_READ_PEAK[0] = stream_read_GBs(device)
         name = workload_name(args.nodes, args.entries, C)
         if not sharded_path:
             launch_s = (sum(step_ms) / len(step_ms)) / 1e3 / K      # one fused SpMM+mix launch (+ its long-row tail)

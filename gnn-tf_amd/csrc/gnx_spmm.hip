@@ -692,6 +692,23 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4 *__restrict__ s
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// read-only counterpart: every lane keeps four 16-byte loads in flight and folds them into one float per block -- the SpMM is
+// almost all reads, so this is the closer yardstick for it
+__global__ __launch_bounds__(256) void k_stream_read(const f32x4 *__restrict__ src, int64_t n4, float *__restrict__ sink) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n4; i += stride) acc += src[i];
+    float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sink + blockIdx.x % 64, v);
+}
+
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
 inline bool aligned(const void *p, size_t a) { return p == nullptr || ((uintptr_t)p % a) == 0; }
@@ -1072,6 +1089,15 @@ int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *st
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_dst && aligned(d_src, 16) && aligned(d_dst, 16), "gnx_stream_copy: NULL or unaligned pointer");
     hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst, n_floats / 4);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void *stream) {
+    GNX_CHECK_ARG(n_floats >= 0 && n_floats % 4 == 0, "gnx_stream_read: the length must be a multiple of 4 floats");
+    if (n_floats == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_src && d_sink64 && aligned(d_src, 16), "gnx_stream_read: NULL or unaligned pointer");
+    hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, n_floats / 4, d_sink64);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }

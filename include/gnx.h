@@ -268,6 +268,8 @@ int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t
 /* Measurement aid: a float4 streaming copy d_dst[0..n) = d_src[0..n) (n a multiple of 4, 16-byte aligned pointers).
  * bench.py times it next to the propagation as the measured-peak HBM rate (read + write bytes per second). */
 int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *stream);
+/* The read-only yardstick: streams d_src[0..n) once and folds it into d_sink64 [64 floats] (accumulated, not cleared). */
+int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void *stream);
 
 /* Name of the SpMM kernel the last gnx_spmm/_t call on this handle dispatched (static
  * string; for profiles and tests). */
