@@ -204,6 +204,16 @@ class GCNLayer(Layer):
         return gcn.dropout(affine(aggregated_features, self.W, self.b, self.activation), self.dropout)
 
 
+class GCNSpectralPreservingLayer(GCNLayer):
+    """gcn.py:92-105: the GCN layer with its bias taken back out after the activation and the surviving half of the dropout
+    doubled -- 2 * dropout(act((A.X).W + b) - b).  Same kernels as GCNLayer (the SpMM, then the matrix-core transform with the
+    bias and a relu fused); the correction is an elementwise tail."""
+
+    def __forward__(self, gcn, features):
+        activated = affine(sparse.spmm(gcn.get_adjacency(self.graph_dropout), features), self.W, self.b, self.activation)
+        return 2 * gcn.dropout(activated - self.b, self.dropout)
+
+
 class GCN(GNN):
     """gcn.py:108-113 (the last layer keeps the default relu, as in the reference)."""
 
@@ -244,6 +254,24 @@ class GCNIILayer(Layer):
             return gcn.dropout(out if fused_act else self.activation(out), self.dropout)
         tradeoff = sparse.ppr_step(adjacency, features, self.H0.value, self.a)
         return gcn.dropout(self.activation(torch.matmul(tradeoff, transform)), self.dropout)
+
+
+class GCNIISpectralPreservingLayer(GCNIILayer):
+    """gcn.py:30-51: GCNIILayer with a bias added before the activation and removed after it, and the dropout's survivors
+    doubled: 2 * dropout(act(T.M + bias) - bias), T = (1-a) A.H + a H0, M = (1-b) I + b W.  The propagation + mix is the fused
+    SpMM kernel; the transform carries the bias and the relu in the matrix-core kernel's epilogue."""
+
+    def __build__(self, architecture, H0, a, l, k=0, **kwargs):
+        shape = super().__build__(architecture, H0, a, l, k, **kwargs)
+        self.bias = architecture.create_var((1, shape[1]), "zero")
+        return shape
+
+    def __forward__(self, gcn, features):
+        b = self.beta_transformer(self.l / (self.k + 1))
+        eye = torch.eye(self.W.shape[1], device=self.W.device, dtype=self.W.dtype)
+        tradeoff = sparse.ppr_step(gcn.get_adjacency(self.graph_dropout), features, self.H0.value, self.a)
+        activated = affine(tradeoff, (1 - b) * eye + b * self.W, self.bias, self.activation)
+        return 2 * gcn.dropout(activated - self.bias, self.dropout)
 
 
 class GCNII(GNN):

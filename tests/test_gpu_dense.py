@@ -289,3 +289,42 @@ def test_ngcf_model(gnntf):
     emb.training_mode(False)
     with torch.no_grad():
         assert emb(emb.features).shape == (3 * n, 8)
+
+
+def test_spectral_preserving_layer_variants(gnntf):
+    """gcn.py:30-51, 92-105 through layer_type=: 2 * dropout(act(z + b) - b) over the same kernels, against numpy in eval mode."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(900, 7000, seed=6)
+    rng = np.random.default_rng(6)
+    X = rng.standard_normal((900, 24)).astype(np.float32)
+    ai, av = orc.get_adjacency(coo, vals, shape, dtype=np.float64)
+    gcn = gnntf.GCN(gnntf.SparseCOO(coo, vals, shape), X, num_classes=5, latent_dims=[16], layer_type=gnntf.GCNSpectralPreservingLayer)
+    gcn.reset()
+    H = X.astype(np.float64)
+    for layer in gcn.layers():
+        with torch.no_grad():
+            layer.b.copy_(dev(rng.uniform(-0.3, 0.3, size=tuple(layer.b.shape)).astype(np.float32)))
+        W, b = layer.W.detach().cpu().numpy().astype(np.float64), layer.b.detach().cpu().numpy().astype(np.float64)
+        H = 2 * (np.maximum(orc.sparse_dense_matmul(ai, av, shape, H) @ W + b, 0) - b)
+    gcn.training_mode(False)
+    with torch.no_grad():
+        np.testing.assert_allclose(gcn(gcn.features).cpu().numpy(), H, rtol=RTOL, atol=1e-4)
+    model = gnntf.GCNII(gnntf.SparseCOO(coo, vals, shape), X, num_classes=5, latent_dims=[32], iterations=3,
+                        layer_type=gnntf.GCNIISpectralPreservingLayer)
+    model.reset()
+    convs = [l for l in model.layers() if isinstance(l, gnntf.GCNIISpectralPreservingLayer)]
+    dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
+    for l in convs:
+        with torch.no_grad():
+            l.W.copy_(dev((rng.standard_normal((32, 32)) * 0.2).astype(np.float32)))
+            l.bias.copy_(dev(rng.uniform(-0.2, 0.2, size=(1, 32)).astype(np.float32)))
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    H0 = np.maximum(X.astype(np.float64) @ f64(dense[0].W) + f64(dense[0].b), 0)
+    H = H0
+    for k, l in enumerate(convs):
+        beta = np.log1p(0.5 / (k + 1))
+        T = orc.ppr_iteration(ai, av, shape, H, H0, 0.1)
+        H = 2 * (np.maximum(T @ ((1 - beta) * np.eye(32) + beta * f64(l.W)) + f64(l.bias), 0) - f64(l.bias))
+    want = H @ f64(dense[1].W) + f64(dense[1].b)
+    model.training_mode(False)
+    with torch.no_grad():
+        np.testing.assert_allclose(model(model.features).cpu().numpy(), want, rtol=RTOL, atol=1e-4)
