@@ -81,6 +81,7 @@ struct gnx_graph {
     float *partial = nullptr;
     size_t partial_bytes = 0;
     float *deg = nullptr;        // [a.n_cols] scratch for column sums / degree scales (lazy)
+    const uint64_t *stream_offset = nullptr;   // optional device counter added to every dropout stream id of this handle
     // degree-relabelled copy of a square matrix (lazy; narrow feature widths): vertex a.row_order[i] becomes vertex i, so the
     // rows of the hubs -- which most gathers hit -- are neighbours in memory and share cache lines
     bool has_r = false;
@@ -121,6 +122,7 @@ __device__ __forceinline__ uint32_t hash_u24(uint64_t seed, uint64_t stream, uin
 struct DropFuse {
     const float *D;        // degree scales of this (seed, stream); null = not fused
     uint64_t seed, stream;
+    const uint64_t *offset; // optional device counter added to the stream id (gnx_graph_set_dropout_counter)
     uint32_t thr;          // keep iff hash >= thr
     float scale;           // 1 / (1 - p)
     int transposed;        // the structure walked is the transpose: its entry (r, c) is A[c][r]
@@ -128,7 +130,8 @@ struct DropFuse {
 
 __device__ __forceinline__ float dropped_weight(const DropFuse &f, float raw, int64_t r, int64_t c) {
     const int64_t ar = f.transposed ? c : r, ac = f.transposed ? r : c;      // the entry's (row, col) in A
-    if (hash_u24(f.seed, f.stream, (uint64_t)ar, (uint64_t)ac, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
+    const uint64_t stream = f.stream + (f.offset ? *f.offset : 0);
+    if (hash_u24(f.seed, stream, (uint64_t)ar, (uint64_t)ac, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
     return (f.D[ar] * (raw * f.scale)) * f.D[ac];
 }
 

@@ -12,22 +12,25 @@ inline unsigned blocks_for(int64_t n, int bs = 256) { return (unsigned)((n + bs 
 
 struct Drop {
     uint64_t seed, stream;
+    const uint64_t *offset;    // optional device counter added to the stream id (graph-captured training steps)
     uint32_t thr;    // keep iff hash >= thr
     float scale;     // 1/(1-p)
     const float *e_vals;       // entry values (null when no duplicates)
     const int64_t *slot_ptr;   // entry range per slot (null when no duplicates)
 };
 
+__device__ __forceinline__ uint64_t stream_of(const Drop &d) { return d.stream + (d.offset ? *d.offset : 0); }
+
 // value of coalesced slot k after per-entry dropout (layered.py:50: kept * 1/(1-p), dropped -> 0)
 template <bool DROPOUT>
 __device__ __forceinline__ float slot_value(const float *__restrict__ raw, const Drop &d, int64_t k, int32_t row, int32_t col) {
     if (!DROPOUT) return raw[k];
     if (d.slot_ptr == nullptr)
-        return hash_u24(d.seed, d.stream, (uint64_t)row, (uint64_t)col, 0) >= d.thr ? raw[k] * d.scale : 0.f;
+        return hash_u24(d.seed, stream_of(d), (uint64_t)row, (uint64_t)col, 0) >= d.thr ? raw[k] * d.scale : 0.f;
     float acc = 0.f;
     const int64_t b = d.slot_ptr[k], e = d.slot_ptr[k + 1];
     for (int64_t i = b; i < e; ++i)
-        if (hash_u24(d.seed, d.stream, (uint64_t)row, (uint64_t)col, (uint64_t)(i - b)) >= d.thr) acc += d.e_vals[i] * d.scale;
+        if (hash_u24(d.seed, stream_of(d), (uint64_t)row, (uint64_t)col, (uint64_t)(i - b)) >= d.thr) acc += d.e_vals[i] * d.scale;
     return acc;
 }
 
@@ -39,7 +42,7 @@ __device__ __forceinline__ float t_value(const float *__restrict__ raw, const fl
     if (d.slot_ptr != nullptr) return slot_value<DROPOUT>(raw, d, t_perm[p], row, col);
     const float v = t_raw[p];
     if (!DROPOUT) return v;
-    return hash_u24(d.seed, d.stream, (uint64_t)row, (uint64_t)col, 0) >= d.thr ? v * d.scale : 0.f;
+    return hash_u24(d.seed, stream_of(d), (uint64_t)row, (uint64_t)col, 0) >= d.thr ? v * d.scale : 0.f;
 }
 
 // column sums over the transposed structure: 8 lanes per column, fixed reduction tree.
@@ -106,7 +109,7 @@ __global__ void k_colsum_short_multi(const int64_t *__restrict__ t_rowptr, const
                 const float v = t_raw[p] * d.scale;
                 const uint64_t row = (uint64_t)t_colidx[p];
 #pragma unroll
-                for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, d.stream + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
+                for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, stream_of(d) + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
             }
     }
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void k_colsum_long_multi(const int64_t *__rest
         const float v = t_raw[p] * d.scale;
         const uint64_t row = (uint64_t)t_colidx[p];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, d.stream + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
+        for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, stream_of(d) + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -196,7 +199,7 @@ __global__ void k_diag(const float *__restrict__ deg, int64_t n, int mode /*0: o
 
 int make_drop(gnx_graph *g, float p, uint64_t seed, uint64_t stream_id, Drop &d) {
     GNX_CHECK_ARG(p >= 0.f && p < 1.f, "dropout rate %g outside [0, 1)", (double)p);
-    d.seed = seed; d.stream = stream_id;
+    d.seed = seed; d.stream = stream_id; d.offset = g->stream_offset;
     d.thr = (uint32_t)((double)p * 16777216.0);
     d.scale = 1.0f / (1.0f - p);
     d.e_vals = g->has_dups ? g->e_vals : nullptr;
@@ -213,6 +216,12 @@ int ensure_deg(gnx_graph *g) {
 }  // namespace
 
 extern "C" {
+
+int gnx_graph_set_dropout_counter(gnx_graph_t g, const uint64_t *d_counter) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_set_dropout_counter: NULL handle");
+    g->stream_offset = d_counter;
+    return GNX_OK;
+}
 
 int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t stream_id, float *d_colsum_out, void *stream) {
     GNX_CHECK_ARG(g != nullptr && d_colsum_out != nullptr, "gnx_graph_colsum: NULL argument");

@@ -942,7 +942,7 @@ int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t 
     p.vals = transposed ? g->t_raw : g->raw_vals;
     p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
     p.out = d_out; p.ldo = ldo; p.C = (int)C;
-    p.fuse.D = d_D; p.fuse.seed = seed; p.fuse.stream = stream_id;
+    p.fuse.D = d_D; p.fuse.seed = seed; p.fuse.stream = stream_id; p.fuse.offset = g->stream_offset;
     p.fuse.thr = (uint32_t)((double)dropout_p * 16777216.0);
     p.fuse.scale = 1.0f / (1.0f - dropout_p);
     p.fuse.transposed = transposed ? 1 : 0;

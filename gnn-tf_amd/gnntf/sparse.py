@@ -109,6 +109,14 @@ class DeviceGraph:
     def last_kernel(self) -> str:
         return (nat.lib().gnx_graph_last_kernel(self._h) or b"").decode()
 
+    def set_dropout_counter(self, counter):
+        """``counter``: a one-element int64 device tensor added to every dropout stream id used with this graph (read by the
+        kernels when they run), or None.  Lets a captured training step draw fresh masks on every replay."""
+        if counter is not None and (counter.dtype != torch.int64 or counter.numel() != 1 or counter.device != self.device):
+            raise Exception("set_dropout_counter: needs a one-element int64 tensor on the graph's device")
+        self._counter = counter                                   # keep it alive while the handle points at it
+        nat.check(nat.lib().gnx_graph_set_dropout_counter(self._h, nat.ptr(counter)))
+
     def __del__(self):
         try:
             if self._h:

@@ -166,8 +166,15 @@ class Trainable(Layered):
               epochs: int = 2000,
               degradation=lambda epoch: 1,
               batches: int = 1,
-              optimizer=None):
+              optimizer=None,
+              capture: bool = False):
+        """trainable.py:41-52.  ``capture=True`` (not in the reference; device models with fixed index lists only) records
+        ONE training step and ONE validation forward as hipGraphs and replays them every epoch: on small graphs an epoch is
+        ~200 kernel launches of a few microseconds each, and the host loop around them is what takes the time."""
         self.reset()
+        if capture:
+            return self._train_captured(train, valid, test, patience, learning_rate, regularization, verbose, epochs, degradation,
+                                        batches, optimizer)
         optimizer = self._make_optimizer(optimizer, learning_rate)
         judge = train if valid is None else valid
         objective = _Objective(self, train, regularization)
@@ -185,6 +192,102 @@ class Trainable(Layered):
             if best.exhausted:
                 break
         best.restore()
+        self._fast_predict = None
+        print('\r')
+
+    # ---- the same loop with the device work of an epoch replayed from two hipGraphs -------------------------------------------
+    def _dropout_graphs(self):
+        """Every DeviceGraph whose kernels draw edge / input-dropout masks for this model."""
+        graphs = [self.graph] if hasattr(self, "graph") else []
+        rows = self._input_features()
+        if rows is not self.features:
+            graphs.append(rows.graph)
+        return graphs
+
+    def _train_captured(self, train, valid, test, patience, learning_rate, regularization, verbose, epochs, degradation, batches,
+                        optimizer):
+        if not self.features.is_cuda:
+            raise Exception("train(capture=True) needs the model on the GPU")
+        if optimizer is not None and isinstance(optimizer, torch.optim.Optimizer):
+            raise Exception("train(capture=True) builds its own capturable optimizer: pass a factory or nothing")
+        device = self.features.device
+        params = [v.var for v in self.vars() if v.trainable]
+        make_optimizer = (lambda: optimizer(params)) if optimizer is not None else \
+            (lambda: torch.optim.Adam(params, lr=learning_rate, eps=1e-7, capturable=True))
+        judge = train if valid is None else valid
+        objective = _Objective(self, train, regularization)
+        scale = torch.ones((), dtype=torch.float32, device=device)           # degradation(epoch), refreshed before every replay
+        counter = torch.zeros(1, dtype=torch.int64, device=device)           # added to every dropout stream id on the device
+        graphs = self._dropout_graphs()
+        for g in graphs:
+            g.set_dropout_counter(counter)
+
+        def train_step(opt):
+            with self:
+                opt.zero_grad(set_to_none=True)
+                value = objective()
+                (value * scale).backward()
+                opt.step()
+            return value
+
+        def validate():
+            with torch.no_grad():
+                logits = self(self.features)
+                return logits, judge.loss(logits)
+
+        try:
+            # warm-up on a side stream (lazy allocations of the library, index uploads, autograd workspaces), then undo it:
+            # parameters, the mask numbering and the optimizer state start the captured run exactly where an eager run starts
+            start = [v.identity() for v in self.vars()]
+            first_mask = self._mask_calls
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                throwaway = make_optimizer()
+                for _ in range(2):
+                    train_step(throwaway)
+                    validate()
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+            for v, value in zip(self.vars(), start):
+                v.assign(value)
+            masks_per_step = (self._mask_calls - first_mask) // 2
+            self._mask_calls = first_mask
+            optimizer = make_optimizer()
+            optimizer.zero_grad(set_to_none=True)
+            step_graph, eval_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(step_graph):
+                fitted_value = train_step(optimizer)
+                counter.add_(masks_per_step)
+            self._mask_calls = first_mask                                    # the device counter does the numbering from here on
+            with torch.cuda.graph(eval_graph):
+                logits, held_out_value = validate()
+        except Exception as error:
+            for g in graphs:
+                g.set_dropout_counter(None)
+            raise Exception("train(capture=True): this model / task cannot be recorded as a device graph (" + str(error) + ")")
+        counter.zero_()
+        best = _BestSoFar(self.vars(), patience)
+        steps = 0
+        for epoch in range(epochs):
+            self._fast_predict = None
+            scale.fill_(float(degradation(epoch)))
+            for _ in range(batches):
+                step_graph.replay()
+                steps += 1
+            eval_graph.replay()
+            held_out = float(held_out_value)                                # the one synchronisation of the epoch
+            if best.observe(held_out):
+                if verbose:
+                    self._report(epoch, best.countdown, float(fitted_value) * batches, held_out, logits, train, judge, test)
+                best.rearm()
+            if best.exhausted:
+                break
+        best.restore()
+        for g in graphs:
+            g.set_dropout_counter(None)
+        self._mask_calls = first_mask + steps * masks_per_step
+        self._training = False
         self._fast_predict = None
         print('\r')
 

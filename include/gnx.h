@@ -94,6 +94,12 @@ int gnx_graph_export(gnx_graph_t g, int64_t *d_rowptr_out, int32_t *d_colidx_out
 int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed,
                         uint64_t stream_id, float *d_vals_out, float *d_diag_out, void *stream);
 
+/* gnx_graph_set_dropout_counter: from now on every dropout stream id used with this handle is `stream_id + *d_counter`
+ * (d_counter: one uint64 in device memory, read by the kernels when they run; NULL switches it off).  This is what lets a
+ * whole training step be captured ONCE in a hipGraph and replayed every epoch with fresh masks: the ids baked into the
+ * captured launches stay fixed, the step's last node advances the counter (layered.py:47-50 draws new masks per call). */
+int gnx_graph_set_dropout_counter(gnx_graph_t g, const uint64_t *d_counter);
+
 /* gnx_graph_normalize_t: the same normalisation, but the values are written in the order of the TRANSPOSED
  * structure (the order gnx_spmm_tv consumes).  The backward pass of a training step only needs A_hat^T, so it
  * regenerates the iteration's dropped adjacency straight into this order instead of permuting a CSR-order

@@ -90,3 +90,43 @@ def test_whole_model_training_step_matches_dense_float64(gnntf, fused):
         scale = np.abs(w_).max()
         np.testing.assert_allclose(g_, w_, rtol=1e-3, atol=2e-5 * scale, err_msg=name)
     assert np.abs(want[1]).max() > 1e-4 and np.abs(want[3]).max() > 1e-4                                # the gradients are not trivially zero
+
+
+def test_captured_training_equals_eager(gnntf):
+    """train(capture=True): one training step + one validation forward recorded as hipGraphs and replayed per epoch.  With edge
+    dropout as the only randomness (counter RNG: the captured launches keep their stream ids, a device counter advances them
+    per replay) the captured run must follow the eager run: same masks, same parameters up to the optimizer's float32 rounding."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(800, 6000, seed=4)
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((800, 20)).astype(np.float32)
+    labels = rng.integers(0, 4, size=800)
+    train, valid = np.arange(0, 200), np.arange(200, 400)
+
+    def build():
+        gnntf.set_seed(11)
+        torch.manual_seed(3)
+        model = gnntf.GNN(gnntf.SparseCOO(coo, vals, shape), X)
+        model.add(gnntf.Dense(16, activation=gnntf.relu))                       # no feature dropout: torch's generator stays out of it
+        H0 = model.add(gnntf.Dense(4, regularize=False))
+        for _ in range(4):
+            model.add(gnntf.PPRIteration(H0, 0.1, graph_dropout=0.5))
+        return model
+
+    results = []
+    for capture in (False, True):
+        model = build()
+        torch.manual_seed(5)                                                    # reset() draws the initial weights from here
+        model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
+                    epochs=12, patience=50, capture=capture)
+        results.append([v.var.detach().cpu().numpy().copy() for v in model.vars()] + [model._mask_calls])
+    assert results[0][-1] == results[1][-1] == 12 * 4                           # 4 edge-dropout masks per step, 12 steps
+    for eager, captured in zip(results[0][:-1], results[1][:-1]):
+        np.testing.assert_allclose(captured, eager, rtol=2e-3, atol=2e-5)
+    # the reference model with all its dropouts: trains, predicts, and a sampler-driven task is refused with a clear message
+    gnntf.set_seed(0)
+    appnp = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=4, fused=True)
+    appnp.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
+                epochs=20, patience=20, capture=True)
+    assert appnp.predict(gnntf.NodeClassification(list(range(400, 800)))).shape[0] == 400 and not appnp.is_training()
+    with pytest.raises(Exception, match="capture=True"):
+        gnntf.MLP(torch.zeros(4, 3), 2).train(train=gnntf.NodeClassification([0], [0]), epochs=1, capture=True)
