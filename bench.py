@@ -320,6 +320,29 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         X64 = torch.randn(g3.n_rows, 64, device=device)
         t128 = median_ms(lambda: gnntf.spmm(adj3, X), reps=20, warm=5)
         t64 = median_ms(lambda: gnntf.spmm(adj3, X64), reps=20, warm=5)
+    # config 2: Cora-shaped APPNP (N = 2708, F = 1433 at 1.3 % density, C = 7, K = 10): the launch-latency regime -- ms per training
+    # epoch of architecture.train(), eager and replayed from hipGraphs (train(capture=True)), and the eval forward
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import graphs as test_graphs
+    coo, vals, shape, Xc = test_graphs.cora_shaped(seed=0)
+    labels = np.random.default_rng(0).integers(0, 7, size=shape[0])
+    tr, va = list(range(140)), list(range(140, 640))
+    tasks = lambda: dict(train=gnntf.NodeClassification(tr, labels[tr]), valid=gnntf.NodeClassification(va, labels[va]))
+    cora = {}
+    for capture in (False, True):
+        gnntf.set_seed(0)
+        m2 = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), Xc, num_classes=7)
+        m2.train(epochs=5, patience=5, capture=capture, **tasks())
+        spans = []
+        for epochs in (50, 150):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m2.train(epochs=epochs, patience=1000, capture=capture, **tasks())
+            torch.cuda.synchronize(); spans.append(time.perf_counter() - t0)
+        cora["captured_train_ms_per_epoch" if capture else "train_ms_per_epoch"] = (spans[1] - spans[0]) / 100 * 1e3
+    with torch.no_grad():
+        cora["eval_forward_ms"] = median_ms(lambda: m2(m2.features), reps=50, warm=5)
+    out["config2_cora_shaped_appnp"] = cora
     out["config3_arxiv_shaped_gcn"] = {"nodes": g3.n_rows, "entries": g3.nnz, "forward_ms": t_fwd, "spmm128_ms": t128, "spmm64_ms": t64,
                                        "spmm128_edges_per_s": g3.nnz / t128 * 1e3, "spmm64_edges_per_s": g3.nnz / t64 * 1e3}
     return out

@@ -242,10 +242,10 @@ class Trainable(Layered):
             first_mask = self._mask_calls
             side = torch.cuda.Stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
+            optimizer = make_optimizer()
             with torch.cuda.stream(side):
-                throwaway = make_optimizer()
-                for _ in range(2):
-                    train_step(throwaway)
+                for _ in range(2):                                          # also creates the optimizer's state tensors: their
+                    train_step(optimizer)                                   # initialisation must not end up inside the graph
                     validate()
             torch.cuda.current_stream(device).wait_stream(side)
             torch.cuda.synchronize(device)
@@ -253,7 +253,10 @@ class Trainable(Layered):
                 v.assign(value)
             masks_per_step = (self._mask_calls - first_mask) // 2
             self._mask_calls = first_mask
-            optimizer = make_optimizer()
+            for state in optimizer.state.values():                          # back to a fresh optimizer: moments and step counts zero
+                for item in state.values():
+                    if isinstance(item, torch.Tensor):
+                        item.zero_()
             optimizer.zero_grad(set_to_none=True)
             step_graph, eval_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(step_graph):

@@ -29,6 +29,17 @@ for fused in (False, True):
         for _ in range(100): model(model.features)
         torch.cuda.synchronize()
     out["eval_forward_ms_fused" if fused else "eval_forward_ms_layers"] = (time.time() - t0) * 10
+for fused in (False, True):                                 # the same epochs replayed from hipGraphs (train(capture=True))
+    gnntf.set_seed(0)
+    model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, fused=fused)
+    model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]), epochs=5, patience=5, capture=True)
+    times = []
+    for epochs in (100, 300):
+        torch.cuda.synchronize(); t0 = time.time()
+        model.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]), epochs=epochs, patience=1000, capture=True)
+        torch.cuda.synchronize(); times.append(time.time() - t0)
+    out["captured_train_ms_per_epoch_fused" if fused else "captured_train_ms_per_epoch_layers"] = (times[1] - times[0]) / 200 * 1e3   # capture cost cancels
+    out["capture_setup_ms_fused" if fused else "capture_setup_ms_layers"] = (times[0] - 100 * (times[1] - times[0]) / 200) * 1e3
 dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
 weights = [(l.W.detach().cpu().numpy(), l.b.detach().cpu().numpy()) for l in dense]
 t0 = time.time()
