@@ -120,14 +120,16 @@ __global__ void k_flag_long(const int64_t *__restrict__ rowptr, int64_t n_rows, 
     cnt[r] = lg ? (d + LONG_CHUNK - 1) / LONG_CHUNK : 0;
 }
 
-// sort key of the degree-binned row order: 255 - min(entries, 255), so an ascending stable sort
-// puts the heaviest rows first and keeps ascending row ids inside a bin
-__global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows, uint8_t *__restrict__ keys,
+// sort key of the degree-binned row order: ORDER_CLAMP - min(entries, ORDER_CLAMP), so an ascending stable sort puts the
+// heaviest rows first and keeps ascending row ids inside a bin.  The clamp covers every row the sub-wave kernels take
+// (up to LONG_ROW entries): the rows that share a wave then have EQUAL lengths, also in the 256..512 range
+constexpr int ORDER_CLAMP = LONG_ROW < 65535 ? LONG_ROW : 65535;
+__global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows, uint16_t *__restrict__ keys,
                              int32_t *__restrict__ ids) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     int64_t d = rowptr[r + 1] - rowptr[r];
-    keys[r] = (uint8_t)(255 - (d < 255 ? d : 255));
+    keys[r] = (uint16_t)(ORDER_CLAMP - (d < ORDER_CLAMP ? d : ORDER_CLAMP));
     ids[r] = (int32_t)r;
 }
 
@@ -213,16 +215,17 @@ int build_long_plan(Csr &m, hipStream_t s) {
     if (m.n_rows == 0) return GNX_OK;
     {   // degree-binned row order
         DevBuf k0, k1, ids, t;
-        GNX_HIP(k0.alloc(m.n_rows)); GNX_HIP(k1.alloc(m.n_rows)); GNX_HIP(ids.alloc(m.n_rows * sizeof(int32_t)));
+        GNX_HIP(k0.alloc(m.n_rows * 2)); GNX_HIP(k1.alloc(m.n_rows * 2)); GNX_HIP(ids.alloc(m.n_rows * sizeof(int32_t)));
         GNX_HIP(hipMalloc((void **)&m.row_order, m.n_rows * sizeof(int32_t)));
-        hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, k0.as<uint8_t>(),
+        hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, k0.as<uint16_t>(),
                            ids.as<int32_t>());
+        const unsigned key_bits = bits_for((uint64_t)ORDER_CLAMP + 1);
         size_t tb = 0;
-        GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint8_t>(), k1.as<uint8_t>(), ids.as<int32_t>(), m.row_order,
-                                          (size_t)m.n_rows, 0u, 8u, s));
+        GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint16_t>(), k1.as<uint16_t>(), ids.as<int32_t>(), m.row_order,
+                                          (size_t)m.n_rows, 0u, key_bits, s));
         GNX_HIP(t.alloc(tb));
-        GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint8_t>(), k1.as<uint8_t>(), ids.as<int32_t>(), m.row_order,
-                                          (size_t)m.n_rows, 0u, 8u, s));
+        GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint16_t>(), k1.as<uint16_t>(), ids.as<int32_t>(), m.row_order,
+                                          (size_t)m.n_rows, 0u, key_bits, s));
         GNX_HIP(hipStreamSynchronize(s));
     }
     if (m.nnz == 0) return GNX_OK;
