@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the N = 1 line")
+    ap.add_argument("--no-alt-grid", action="store_true", help="N > 1: skip the second field (the same graph on feature slices, no exchange)")
     args = ap.parse_args()
     if args.nodes or args.entries or args.feats:
         base = WORKLOADS[args.workload if args.workload in WORKLOADS else "config5"]
@@ -450,6 +451,34 @@ def main():
                         GBs_per_link_and_direction=halo_bytes / max(t_x, 1e-9) / 1e9 / max(pv - 1, 1),
                         pull_only_bytes_per_rank_per_iteration=halo["max_pull_only_rows"] * C_local * 4)
 
+    # N > 1, second field (never the headline): the SAME graph replicated on every rank, each rank propagating C / N of the feature
+    # columns -- no exchange at all, graph memory and prep grow with N.  Tells how far the vertex blocks are from a link-free bound.
+    alt = None
+    if world > 1 and not args.no_alt_grid and not args.grid and C % world == 0:
+        kernel_blocks = sg.graph.last_kernel()
+        del state, sg, H0
+        torch.cuda.empty_cache()
+        from gnntf import _native as nat
+        g2, adj2, _ = build_single(args, device)
+        Cs = C // world
+        H2 = torch.rand(g2.n_rows, Cs, device=device) * 2 - 1
+        out2, work2 = torch.empty_like(H2), torch.empty_like(H2)
+
+        def step2():
+            nat.check(nat.lib().gnx_appnp_propagate(g2.handle, nat.ptr(adj2.vals), None, nat.ptr(H2), a, K, Cs, nat.ptr(out2), nat.ptr(work2),
+                                                    nat.current_stream()))
+        steps2 = max(2, args.steps // 4)
+        e2, _ = timed_steps(step2, steps2, 1, barrier)
+        t2 = torch.tensor([e2], device=device, dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        alt = {"grid": f"1_vertex_block_x_{world}_feature_slices", "value": g2.nnz * K * steps2 / float(t2.item()), "unit": "edges/s",
+               "ms_per_step": float(t2.item()) / steps2 * 1e3, "columns_per_rank": Cs, "kernel": g2.last_kernel(),
+               "note": "graph replicated on every rank (memory and prep x N), no data-path communication; reported beside the headline "
+                       "vertex-block grid, never instead of it"}
+        del g2, adj2, H2, out2, work2
+    else:
+        kernel_blocks = sg.graph.last_kernel() if sharded_path else None
+
     if rank == 0:
         edges = nnz_global * K * args.steps
         measured_peak = stream_copy_GBs(device)
@@ -459,7 +488,7 @@ def main():
             launch_s = (sum(step_ms) / len(step_ms)) / 1e3 / K      # one fused SpMM+mix launch (+ its long-row tail)
             roof = roofline_record(n_local, nnz_local, C, launch_s, K, name, measured_peak)
         else:                                                       # this rank's block: kernels alone (no exchange beside them)
-            t_c = sg.time_compute(state, a) if world == 1 else halo["compute_ms_alone"] * 1e-3
+            t_c = halo["compute_ms_alone"] * 1e-3 if world > 1 else sg.time_compute(state, a)
             roof = roofline_record(n_local, nnz_local, C_local, t_c, K, name + f"_block_of_{pv}", measured_peak)
             roof["note"] = "rank 0's vertex block, one iteration's kernels alone (pack + SpMM of every column chunk; no exchange beside them); " + roof["note"]
         result = {
@@ -470,7 +499,8 @@ def main():
                        "global_rows": args.nodes, "stored_entries_total": nnz_global, "rows_per_rank": n_local,
                        "stored_entries_per_rank": nnz_local, "features": C, "iterations": K, "alpha": a,
                        "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
-                       "halo": halo, "prep": prep, "kernel": (sg.graph.last_kernel() if sharded_path else g.last_kernel())},
+                       "halo": halo, "prep": prep, "kernel": (kernel_blocks if sharded_path else g.last_kernel()),
+                       "alt_grid_feature_slices": alt},
             "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:
