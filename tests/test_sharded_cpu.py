@@ -39,9 +39,10 @@ def test_sharded_directed_pattern(world, options):
     launch(world, "directed", options=options)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_strong_scaling_generator(world):
-    """bench.py's N > 1 workload: ONE global graph cut into `world` vertex blocks (rank 0 generates, broadcast)."""
+    """bench.py's N > 1 workload: ONE global graph cut into `world` vertex blocks (rank 0 generates, broadcast); world 8 is
+    the layout of BASELINE config 5 (seven peer regions around the local rows, per-peer pull / push lists)."""
     launch(world, "blocks")
 
 
