@@ -8,7 +8,7 @@
 
 #include "../../include/gnx.h"
 
-#define GNX_VERSION_NUM 101 /* 0.1.1 */
+#define GNX_VERSION_NUM 200 /* 0.2.0 */
 
 namespace gnx {
 
