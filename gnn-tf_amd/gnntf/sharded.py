@@ -671,6 +671,42 @@ class ShardedGraph:
         return out
 
 
+# ---- the layer API on a vertex block ---------------------------------------------------------------------------------
+from .protocol import Layer  # noqa: E402
+
+
+class ShardedPPRLoop(Layer):
+    """The K PPRIteration layers of APPNP (filter.py:34-35) for a model that holds ONE vertex block of the graph: every rank
+    builds the same layer stack over the rows of its block (the Dense layers before it act row by row, so they need no
+    communication), and this layer propagates the block's H0 with the other ranks through ``ShardedGraph.propagate``.
+    Inference (architecture.predict()): eval-mode arithmetic, no autograd through the exchange.
+
+        sg = ShardedGraph(my_entries, vals, bounds)
+        model = gnntf.Trainable(features_of_my_rows)
+        model.add(gnntf.Dense(64, activation=gnntf.relu)); H0 = model.add(gnntf.Dense(num_classes))
+        model.add(ShardedPPRLoop(H0, sg, 0.1, 10))
+        local_labels = model.predict(gnntf.NodeClassification(my_local_node_ids))
+    """
+
+    def __build__(self, architecture, H0: Layer, graph: "ShardedGraph", restart_probability: float = 0.1, iterations: int = 10):
+        if architecture.top_shape()[0] != graph.n_local:
+            raise Exception("ShardedPPRLoop: the architecture must hold this rank's %d rows" % graph.n_local)
+        self.H0, self.graph, self.restart_probability, self.iterations = H0, graph, restart_probability, iterations
+        self._state = None
+        return architecture.top_shape()
+
+    def __forward__(self, architecture, features):
+        H0 = self.H0.value.detach()
+        if self._state is None or tuple(self._state.H0.shape) != tuple(H0.shape):
+            self._state = self.graph.make_state(H0)
+        else:
+            self._state.H0.copy_(H0)
+            if self.graph.row_order is not None:
+                self._state.H0_user.copy_(H0)
+                self._state.H0.copy_(H0.index_select(0, self.graph.row_order))
+        return self.graph.propagate(self._state, self.restart_probability, self.iterations).clone()
+
+
 # ---- synthetic sharded R-MAT (bench.py, N > 1) ------------------------------------------------------------
 def _rmat_pairs(scale, m, gen, device, a=0.57, b=0.19, c=0.19):
     src = torch.zeros(m, dtype=torch.int64, device=device)

@@ -190,6 +190,23 @@ def main():
         exact_order = options["cover"] == "pull" and sg.row_order is None
         tol = (1e-6, 1e-7) if exact_order else (1e-5, 1e-6)
         np.testing.assert_allclose(got_all, single, rtol=tol[0], atol=tol[1])
+    # the layer API on a vertex block (eval mode): Dense layers act row by row, ShardedPPRLoop propagates with the other ranks
+    import gnntf
+    gnntf.set_default_device(dev)
+    torch.manual_seed(7)
+    Wd = (torch.rand(C, 5) - 0.5).to(dev)
+    local = gnntf.Trainable(torch.from_numpy(H0_full[lo:hi]).to(dev))
+    head = local.add(gnntf.Dense(5, bias=False))
+    local.add(sharded.ShardedPPRLoop(head, sg, a, K)) if pf == 1 else None
+    if pf == 1:
+        local.vars()[0].assign(Wd)
+        local.training_mode(False)
+        pred = local.predict(gnntf.NodeClassification(list(range(sg.n_local))))
+        want_all = orc.appnp_propagate(raw_coo, raw_vals, (n, n), H0_full @ Wd.cpu().numpy(), a=a, iterations=K)
+        top2 = np.sort(want_all[lo:hi], axis=1)
+        clear = (top2[:, -1] - top2[:, -2]) > 1e-4                     # rows whose best class is not a float tie
+        assert (pred.cpu().numpy()[clear] == want_all[lo:hi].argmax(1)[clear]).all() and clear.mean() > 0.9
+    gnntf.set_default_device(None)
     if rank == 0:
         print("OK", mode, "world", world, "grid", f"{pv}x{pf}", "nnz", sg.nnz_global, "stats", sg.halo_stats() if False else sg.stats,
               "kernel", sg.graph.last_kernel())
