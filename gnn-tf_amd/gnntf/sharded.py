@@ -675,36 +675,124 @@ class ShardedGraph:
 from .protocol import Layer  # noqa: E402
 
 
+class _BlockLoop(torch.autograd.Function):
+    """The K-iteration loop over a vertex block as one autograd node.  The loop is a polynomial F(A_hat) applied to H0
+    (H_K = (1-a)^K A^K H0 + a sum_{k<K} (1-a)^k A^k H0), so dH0 = F(A_hat)^T g -- and for the symmetric A_hat of an undirected
+    graph that is F(A_hat) g: the backward IS the same sharded propagation, applied to the output gradient."""
+
+    @staticmethod
+    def forward(ctx, H0, layer):
+        ctx.layer = layer
+        return layer._propagate("forward", H0.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.layer._propagate("backward", g.contiguous()), None
+
+
 class ShardedPPRLoop(Layer):
     """The K PPRIteration layers of APPNP (filter.py:34-35) for a model that holds ONE vertex block of the graph: every rank
     builds the same layer stack over the rows of its block (the Dense layers before it act row by row, so they need no
     communication), and this layer propagates the block's H0 with the other ranks through ``ShardedGraph.propagate``.
-    Inference (architecture.predict()): eval-mode arithmetic, no autograd through the exchange.
 
         sg = ShardedGraph(my_entries, vals, bounds)
         model = gnntf.Trainable(features_of_my_rows)
         model.add(gnntf.Dense(64, activation=gnntf.relu)); H0 = model.add(gnntf.Dense(num_classes))
         model.add(ShardedPPRLoop(H0, sg, 0.1, 10))
         local_labels = model.predict(gnntf.NodeClassification(my_local_node_ids))
-    """
 
-    def __build__(self, architecture, H0: Layer, graph: "ShardedGraph", restart_probability: float = 0.1, iterations: int = 10):
+    Training works too when the adjacency is symmetric and constant (an undirected graph, no edge dropout): the backward of
+    the loop is then the loop itself applied to the gradient (see _BlockLoop), the parameter gradients of the row-wise layers
+    are summed over the ranks by ``SummedGradients`` and the task is a ``BlockNodeClassification``."""
+
+    def __build__(self, architecture, H0: Layer, graph: "ShardedGraph", restart_probability: float = 0.1, iterations: int = 10,
+                  symmetric: bool = True):
         if architecture.top_shape()[0] != graph.n_local:
             raise Exception("ShardedPPRLoop: the architecture must hold this rank's %d rows" % graph.n_local)
         self.H0, self.graph, self.restart_probability, self.iterations = H0, graph, restart_probability, iterations
-        self._state = None
+        self.symmetric = symmetric
+        self._states = dict()
         return architecture.top_shape()
 
-    def __forward__(self, architecture, features):
-        H0 = self.H0.value.detach()
-        if self._state is None or tuple(self._state.H0.shape) != tuple(H0.shape):
-            self._state = self.graph.make_state(H0)
+    def _propagate(self, which, H0):
+        state = self._states.get(which)
+        if state is None or tuple(state.H0.shape) != tuple(H0.shape):
+            state = self._states[which] = self.graph.make_state(H0)
+        elif self.graph.row_order is not None:
+            state.H0_user.copy_(H0)
+            state.H0.copy_(H0.index_select(0, self.graph.row_order))
         else:
-            self._state.H0.copy_(H0)
-            if self.graph.row_order is not None:
-                self._state.H0_user.copy_(H0)
-                self._state.H0.copy_(H0.index_select(0, self.graph.row_order))
-        return self.graph.propagate(self._state, self.restart_probability, self.iterations).clone()
+            state.H0.copy_(H0)
+        return self.graph.propagate(state, self.restart_probability, self.iterations).clone()
+
+    def __forward__(self, architecture, features):
+        H0 = self.H0.value
+        if torch.is_grad_enabled() and H0.requires_grad:
+            if not self.symmetric:
+                raise Exception("ShardedPPRLoop: gradients need a symmetric adjacency (the backward reuses the forward propagation)")
+            return _BlockLoop.apply(H0, self)
+        return self._propagate("forward", H0.detach())
+
+
+class SummedGradients:
+    """Optimizer wrapper for models that hold one vertex block each: before every step the gradients of the (replicated)
+    parameters are summed over the ranks, so every rank applies the same update -- what one process holding all rows would
+    compute, given a task that scales its local loss by the GLOBAL item count (BlockNodeClassification).
+    Use as ``architecture.train(..., optimizer=lambda params: SummedGradients(torch.optim.Adam(params, ...), comm))``."""
+
+    def __init__(self, optimizer, comm: Comm):
+        self.optimizer, self.comm = optimizer, comm
+
+    def zero_grad(self, set_to_none=True):
+        self.optimizer.zero_grad(set_to_none=set_to_none)
+
+    def step(self):
+        for group in self.optimizer.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                self.comm.all_reduce(p.grad)
+        self.optimizer.step()
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    @property
+    def state(self):
+        return self.optimizer.state
+
+
+class BlockNodeClassification:
+    """NodeClassification (graph_predictor.py:10-31) over the labelled nodes of ONE vertex block: ``nodes`` are LOCAL row ids.
+    loss() has the GLOBAL mean cross entropy as its value on every rank (so early stopping decides alike everywhere) and this
+    rank's share of it as its gradient (SummedGradients adds the shares up); evaluate() is the global accuracy."""
+
+    def __init__(self, nodes, labels, comm: Comm):
+        from .tasks import NodeClassification
+        self.local = NodeClassification(nodes, labels) if len(nodes) else None
+        self.comm, self.count = comm, len(nodes)
+        t = torch.tensor([float(self.count)], dtype=torch.float64)
+        total = comm.all_reduce(t.to(self._device()) if self._device().type == "cuda" else t)
+        self.total = float(total.item())
+        self.nodes, self.labels = nodes, labels
+
+    def _device(self):
+        from .params import default_device
+        return default_device()
+
+    def predict(self, features):
+        return self.local.predict(features) if self.local is not None else torch.zeros(0, dtype=torch.int64, device=features.device)
+
+    def loss(self, features):
+        share = self.local.loss(features) * (self.count / self.total) if self.local is not None else features.sum() * 0.0
+        everyone = self.comm.all_reduce(share.detach().clone().reshape(1))
+        return share + (everyone.reshape(()) - share.detach())
+
+    def evaluate(self, features):
+        right = float(self.local.evaluate(features)) * self.count if self.local is not None else 0.0
+        t = torch.tensor([right], dtype=torch.float64, device=features.device)
+        return float(self.comm.all_reduce(t).item()) / self.total
 
 
 # ---- synthetic sharded R-MAT (bench.py, N > 1) ------------------------------------------------------------

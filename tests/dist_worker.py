@@ -83,10 +83,81 @@ class OracleBackend:
         return X[idx].contiguous()
 
 
+def train_on_blocks(rank, world, dev, backend):
+    """architecture.train() with every rank holding ONE vertex block (ShardedPPRLoop + SummedGradients +
+    BlockNodeClassification) against single-process dense float64 training of the same model: same parameters afterwards."""
+    import gnntf
+    gnntf.set_default_device(dev)
+    n, F, hidden, classes, K, a, epochs = 600, 10, 8, 4, 6, 0.1, 8
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 5000, seed=8)
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    labels = rng.integers(0, classes, size=n)
+    train_ids, valid_ids = np.arange(0, 240), np.arange(240, 420)
+    bounds = sharded.uniform_bounds(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
+    sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend)
+    model = gnntf.Trainable(torch.from_numpy(X[lo:hi]).to(dev))
+    model.add(gnntf.Dense(hidden, activation=gnntf.relu))
+    head = model.add(gnntf.Dense(classes, regularize=False))
+    model.add(sharded.ShardedPPRLoop(head, sg, a, K))
+    local = lambda ids: ids[(ids >= lo) & (ids < hi)]
+    tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
+    torch.manual_seed(21)                                          # reset() draws the same initial weights on every rank
+    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4 / world,
+                optimizer=lambda params: sharded.SummedGradients(torch.optim.Adam(params, lr=0.01, eps=1e-7), sg.comm))
+    got = [v.var.detach().cpu().numpy().astype(np.float64) for v in model.vars()]
+    accuracy = model.evaluate(tasks[1])
+    # ---- the same training in one process, dense float64 ----------------------------------------------------------------
+    torch.manual_seed(21)
+    ref = gnntf.Layered((n, F))
+    ref.add(gnntf.Dense(hidden, activation=gnntf.relu)); ref.add(gnntf.Dense(classes, regularize=False))
+    ref.reset()
+    W1, b1, W2, b2 = [torch.tensor(v.var.detach().cpu().numpy().astype(np.float64), requires_grad=True) for v in ref.vars()]
+    ai, av = orc.get_adjacency(coo, vals, shape, dtype=np.float64)
+    A = torch.from_numpy(orc.to_dense(ai, av, shape, dtype=np.float64))
+    Xt, yt = torch.from_numpy(X.astype(np.float64)), torch.from_numpy(labels)
+    opt = torch.optim.Adam([W1, b1, W2, b2], lr=0.01, eps=1e-7)
+
+    def forward():
+        H0 = torch.relu(Xt @ W1 + b1) @ W2 + b2
+        H = H0
+        for _ in range(K):
+            H = (A @ H) * (1 - a) + H0 * a
+        return H
+    best, best_params = float("inf"), None
+    for _ in range(epochs):
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(forward()[train_ids], yt[train_ids]) + 5e-4 * ((W1 ** 2).sum() + (b1 ** 2).sum()) / 2
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            out = forward()
+            v = float(torch.nn.functional.cross_entropy(out[valid_ids], yt[valid_ids]))
+        if v < best:
+            best, best_params = v, [p.detach().clone().numpy() for p in (W1, b1, W2, b2)]
+    for name, g_, w_ in zip(("W1", "b1", "W2", "b2"), got, best_params):
+        np.testing.assert_allclose(g_, w_, rtol=2e-3, atol=2e-5, err_msg=name)
+    with torch.no_grad():
+        for p, q in zip((W1, b1, W2, b2), best_params):
+            p.copy_(torch.from_numpy(q))
+        want_acc = float((forward()[valid_ids].argmax(1) == yt[valid_ids]).double().mean())
+    assert abs(accuracy - want_acc) < 0.02, (accuracy, want_acc)
+    gnntf.set_default_device(None)
+    if rank == 0:
+        print("OK train world", world, "valid accuracy", round(accuracy, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     mode = sys.argv[1]
+    if mode == "train":
+        on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
+        return train_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())
     on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"          # GPU box: every rank shares cuda:0, libgnx.so backend
     opts = (sys.argv[3] if len(sys.argv) > 3 else "cover,split,2").split(",")
     options = dict(cover=opts[0], split_rows=opts[1] == "split", chunks=int(opts[2]), keep_entries=True)

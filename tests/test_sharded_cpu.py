@@ -56,6 +56,14 @@ def test_feature_sliced_grid(world, grid):
     launch(world, grid)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_training_on_vertex_blocks(world):
+    """architecture.train() with one vertex block per rank (symmetric constant adjacency): the backward of the K loop is the
+    same sharded propagation applied to the gradient, parameter gradients are summed over the ranks, the task reports global
+    losses -- same parameters as single-process dense float64 training."""
+    launch(world, "train")
+
+
 def test_choose_grid_and_columns():
     """Planning helpers: the grid cost model takes a MEASURED link rate (no built-in default), and the column
     chunks are whole 128-byte lines wherever the width allows."""
@@ -95,7 +103,7 @@ def test_cover_push_mask_properties():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,options", [("slices", "cover,split,2"), ("slices", "pull,whole,1"), ("blocks", "cover,split,2"),
-                                          ("rmat", "cover,whole,2"), ("grid1x2", "cover,split,2")])
+                                          ("rmat", "cover,whole,2"), ("grid1x2", "cover,split,2"), ("train", "cover,split,2")])
 def test_sharded_native_backend_two_ranks_one_gpu(mode, options):
     """The libgnx.so backend on real shards (rectangular CSR over [regions | local | regions], interior / boundary
     handles with row maps, the send CSR, exchange on its own stream): two ranks share cuda:0 and exchange over gloo
