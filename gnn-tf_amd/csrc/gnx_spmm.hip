@@ -747,6 +747,8 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
         if (pipe) GNX_LAUNCH((k_spmm_group<VEC, G, 4, true>), blocks_for(p.n_rows, RPB_), p);         \
         else      GNX_LAUNCH((k_spmm_group<VEC, G, 4, false>), blocks_for(p.n_rows, RPB_), p);        \
     } while (0)
+    // (round 2, one-process A/B at C = 128 / 64: 8 entries in flight per lane 8.86 / 4.57 ms, pipelined 8.98 / 4.37, 2 entries 8.24 / 4.37
+    //  against 8.24 / 4.36 for the shipped 4 -- the sub-wave kernels sit on the bandwidth plateau, not on latency)
     if (lanes > 16) { GNX_GROUP(32, 8, false); return "spmm_group32"; }
     if (lanes > 8)  { GNX_GROUP(16, 16, false); return "spmm_group16"; }
     if (lanes > 4)  { GNX_GROUP(8, 32, true); return "spmm_group8"; }
