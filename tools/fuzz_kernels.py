@@ -34,16 +34,18 @@ for case in range(cases):
         g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, vals, (n, n_cols)), device="cuda:0")
         X = rng.standard_normal((n_cols, C)).astype(np.float32)
         H0 = rng.standard_normal((n, C)).astype(np.float32)
+        longest = int(np.bincount(idx[:, 0], minlength=n).max()) if nnz else 1
+        atol = 2e-4 + 1e-5 * np.sqrt(longest)                                  # float32 sums over a hub row's entries cancel
         if kind == 0:
             relu = rng.random() < 0.3
             got = _launch(gnntf.Adjacency(g), dev(X), dev(H0), 0.8, 0.2, 1 if relu else 0).cpu().numpy()
             want = orc.sparse_dense_matmul(idx, vals.astype(np.float64), (n, n_cols), X.astype(np.float64)) * 0.8 + 0.2 * H0
             want = np.maximum(want, 0) if relu else want
-            np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-4, err_msg=f"spmm case {case}")
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=atol, err_msg=f"spmm case {case}")
             if sq and nnz:
                 gt = _launch(gnntf.Adjacency(g, dev(vals_sorted := g.csr_arrays()[2].cpu().numpy())), dev(H0), None, 1.0, 0.0, 0, transposed=True).cpu().numpy()
                 wt = orc.sparse_dense_matmul(idx[:, ::-1], vals.astype(np.float64), (n_cols, n), H0.astype(np.float64))
-                np.testing.assert_allclose(gt, wt, rtol=1e-4, atol=2e-4, err_msg=f"spmm_t case {case}")
+                np.testing.assert_allclose(gt, wt, rtol=1e-4, atol=2e-4 + 1e-5 * np.sqrt(int(np.bincount(idx[:, 1], minlength=n_cols).max())), err_msg=f"spmm_t case {case}")
             stats["spmm"] += 1
         elif kind == 1 and nnz:
             p = float(rng.choice([0.1, 0.5, 0.9]))
@@ -69,7 +71,7 @@ for case in range(cases):
                 got = gnntf.gcnii_step(adj, dev(X), dev(H0), 0.1, dev(M), relu=True).cpu().numpy()
             ai, av = orc.get_adjacency(idx, vals, (n, n), dtype=np.float64)
             want = np.maximum(orc.ppr_iteration(ai, av, (n, n), X.astype(np.float64), H0.astype(np.float64), 0.1) @ M.astype(np.float64), 0)
-            np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-4, err_msg=f"gcnii case {case}")
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=atol, err_msg=f"gcnii case {case}")
             stats["gcnii"] += 1
         del g
     elif kind in (4, 5):
