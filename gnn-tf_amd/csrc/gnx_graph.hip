@@ -425,6 +425,7 @@ int gnx_graph_destroy(gnx_graph_t g) {
     if (g->t_rowidx) (void)hipFree(g->t_rowidx);
     if (g->partial) (void)hipFree(g->partial);
     if (g->deg) (void)hipFree(g->deg);
+    if (g->blk_col_gid) (void)hipFree(g->blk_col_gid);
     free_csr(g->r);
     if (g->r_perm) (void)hipFree(g->r_perm);
     if (g->r_vals) (void)hipFree(g->r_vals);

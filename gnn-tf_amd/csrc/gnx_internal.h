@@ -82,6 +82,10 @@ struct gnx_graph {
     size_t partial_bytes = 0;
     float *deg = nullptr;        // [a.n_cols] scratch for column sums / degree scales (lazy)
     const uint64_t *stream_offset = nullptr;   // optional device counter added to every dropout stream id of this handle
+    // vertex block of a larger graph (gnx_graph_set_block): dropout draws are keyed by GLOBAL (row, col), and the degree
+    // scale of local row r sits at position blk_row0_buf + r of the per-column scale vector
+    int64_t blk_row0_global = 0, blk_row0_buf = 0;
+    int32_t *blk_col_gid = nullptr;            // [a.n_cols] global vertex id of every column (owned), or null
     // degree-relabelled copy of a square matrix (lazy; narrow feature widths): vertex a.row_order[i] becomes vertex i, so the
     // rows of the hubs -- which most gathers hit -- are neighbours in memory and share cache lines
     bool has_r = false;
@@ -126,13 +130,16 @@ struct DropFuse {
     uint32_t thr;          // keep iff hash >= thr
     float scale;           // 1 / (1 - p)
     int transposed;        // the structure walked is the transpose: its entry (r, c) is A[c][r]
+    int64_t row0_key, row0_D;   // vertex block: global id of row 0 / position of row 0's scale in D (0, 0 otherwise)
+    const int32_t *gid;         // vertex block: global id of every column (null: the column index itself)
 };
 
 __device__ __forceinline__ float dropped_weight(const DropFuse &f, float raw, int64_t r, int64_t c) {
     const int64_t ar = f.transposed ? c : r, ac = f.transposed ? r : c;      // the entry's (row, col) in A
     const uint64_t stream = f.stream + (f.offset ? *f.offset : 0);
-    if (hash_u24(f.seed, stream, (uint64_t)ar, (uint64_t)ac, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
-    return (f.D[ar] * (raw * f.scale)) * f.D[ac];
+    const uint64_t kc = f.gid ? (uint64_t)f.gid[ac] : (uint64_t)ac;
+    if (hash_u24(f.seed, stream, (uint64_t)(ar + f.row0_key), kc, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
+    return (f.D[ar + f.row0_D] * (raw * f.scale)) * f.D[ac];
 }
 
 struct SpmmArgs {

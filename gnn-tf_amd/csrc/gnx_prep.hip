@@ -17,7 +17,13 @@ struct Drop {
     float scale;     // 1/(1-p)
     const float *e_vals;       // entry values (null when no duplicates)
     const int64_t *slot_ptr;   // entry range per slot (null when no duplicates)
+    int64_t row0;              // vertex block (gnx_graph_set_block): global id of row 0, else 0
+    const int32_t *gid;        // vertex block: global id of every column, else null
 };
+
+// the (row, col) the dropout draw of an entry is keyed by: global ids when the handle is a vertex block
+__device__ __forceinline__ uint64_t key_row(const Drop &d, int64_t row) { return (uint64_t)(row + d.row0); }
+__device__ __forceinline__ uint64_t key_col(const Drop &d, int64_t col) { return d.gid ? (uint64_t)d.gid[col] : (uint64_t)col; }
 
 __device__ __forceinline__ uint64_t stream_of(const Drop &d) { return d.stream + (d.offset ? *d.offset : 0); }
 
@@ -26,11 +32,12 @@ template <bool DROPOUT>
 __device__ __forceinline__ float slot_value(const float *__restrict__ raw, const Drop &d, int64_t k, int32_t row, int32_t col) {
     if (!DROPOUT) return raw[k];
     if (d.slot_ptr == nullptr)
-        return hash_u24(d.seed, stream_of(d), (uint64_t)row, (uint64_t)col, 0) >= d.thr ? raw[k] * d.scale : 0.f;
+        return hash_u24(d.seed, stream_of(d), key_row(d, row), key_col(d, col), 0) >= d.thr ? raw[k] * d.scale : 0.f;
     float acc = 0.f;
     const int64_t b = d.slot_ptr[k], e = d.slot_ptr[k + 1];
+    const uint64_t kr = key_row(d, row), kc = key_col(d, col);
     for (int64_t i = b; i < e; ++i)
-        if (hash_u24(d.seed, stream_of(d), (uint64_t)row, (uint64_t)col, (uint64_t)(i - b)) >= d.thr) acc += d.e_vals[i] * d.scale;
+        if (hash_u24(d.seed, stream_of(d), kr, kc, (uint64_t)(i - b)) >= d.thr) acc += d.e_vals[i] * d.scale;
     return acc;
 }
 
@@ -42,7 +49,7 @@ __device__ __forceinline__ float t_value(const float *__restrict__ raw, const fl
     if (d.slot_ptr != nullptr) return slot_value<DROPOUT>(raw, d, t_perm[p], row, col);
     const float v = t_raw[p];
     if (!DROPOUT) return v;
-    return hash_u24(d.seed, stream_of(d), (uint64_t)row, (uint64_t)col, 0) >= d.thr ? v * d.scale : 0.f;
+    return hash_u24(d.seed, stream_of(d), key_row(d, row), key_col(d, col), 0) >= d.thr ? v * d.scale : 0.f;
 }
 
 // column sums over the transposed structure: 8 lanes per column, fixed reduction tree.
@@ -104,13 +111,15 @@ __global__ void k_colsum_short_multi(const int64_t *__restrict__ t_rowptr, const
     if (j < n_cols) {
         const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
         is_long = (e - b) > LONG_ROW;
-        if (!is_long)
+        if (!is_long) {
+            const uint64_t kc = key_col(d, j);
             for (int64_t p = b + sub; p < e; p += 8) {
                 const float v = t_raw[p] * d.scale;
-                const uint64_t row = (uint64_t)t_colidx[p];
+                const uint64_t row = key_row(d, t_colidx[p]);
 #pragma unroll
-                for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, stream_of(d) + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
+                for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, stream_of(d) + s, row, kc, 0) >= d.thr ? v : 0.f;
             }
+        }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -132,11 +141,12 @@ __global__ __launch_bounds__(256) void k_colsum_long_multi(const int64_t *__rest
     float acc[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+    const uint64_t kc = key_col(d, j);
     for (int64_t p = b + threadIdx.x; p < e; p += 256) {
         const float v = t_raw[p] * d.scale;
-        const uint64_t row = (uint64_t)t_colidx[p];
+        const uint64_t row = key_row(d, t_colidx[p]);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, stream_of(d) + s, row, (uint64_t)j, 0) >= d.thr ? v : 0.f;
+        for (int s = 0; s < NS; ++s) acc[s] += hash_u24(d.seed, stream_of(d) + s, row, kc, 0) >= d.thr ? v : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -204,6 +214,7 @@ int make_drop(gnx_graph *g, float p, uint64_t seed, uint64_t stream_id, Drop &d)
     d.scale = 1.0f / (1.0f - p);
     d.e_vals = g->has_dups ? g->e_vals : nullptr;
     d.slot_ptr = g->has_dups ? g->slot_ptr : nullptr;
+    d.row0 = g->blk_row0_global; d.gid = g->blk_col_gid;
     return GNX_OK;
 }
 
@@ -220,6 +231,22 @@ extern "C" {
 int gnx_graph_set_dropout_counter(gnx_graph_t g, const uint64_t *d_counter) {
     GNX_CHECK_ARG(g != nullptr, "gnx_graph_set_dropout_counter: NULL handle");
     g->stream_offset = d_counter;
+    return GNX_OK;
+}
+
+int gnx_graph_set_block(gnx_graph_t g, int64_t row0_global, int64_t row0_buf, const int32_t *d_col_gid, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_set_block: NULL handle");
+    if (d_col_gid == nullptr) {                              // back to a stand-alone graph
+        if (g->blk_col_gid) (void)hipFree(g->blk_col_gid);
+        g->blk_col_gid = nullptr; g->blk_row0_global = 0; g->blk_row0_buf = 0;
+        return GNX_OK;
+    }
+    GNX_CHECK_ARG(row0_global >= 0 && row0_buf >= 0 && row0_buf + g->a.n_rows <= g->a.n_cols,
+                  "gnx_graph_set_block: the %lld rows do not fit behind column %lld of %lld", (long long)g->a.n_rows,
+                  (long long)row0_buf, (long long)g->a.n_cols);
+    if (!g->blk_col_gid) GNX_HIP(hipMalloc((void **)&g->blk_col_gid, (g->a.n_cols ? g->a.n_cols : 1) * sizeof(int32_t)));
+    GNX_HIP(hipMemcpyAsync(g->blk_col_gid, d_col_gid, g->a.n_cols * sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    g->blk_row0_global = row0_global; g->blk_row0_buf = row0_buf;
     return GNX_OK;
 }
 

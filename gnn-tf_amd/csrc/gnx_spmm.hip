@@ -178,7 +178,7 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
         if (nt) vload_nt<VEC>(h0, p.H0 + hrow * p.ldh0 + c);
         else vload<VEC>(h0, p.H0 + hrow * p.ldh0 + c);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o[v] = acc[v] * p.beta + h0[v] * p.alpha;
+        for (int v = 0; v < VEC; ++v) o[v] = fmaf(acc[v], p.beta, h0[v] * p.alpha);   // spelled out: every kernel variant rounds alike
     } else {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = acc[v] * p.beta;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const
             float h0[4];
             vload<4>(h0, p.H0 + row * p.ldh0 + c);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) acc[v] = acc[v] * p.beta + h0[v] * p.alpha;      // filter.py:20-21 / gcn.py:25
+            for (int v = 0; v < 4; ++v) acc[v] = fmaf(acc[v], p.beta, h0[v] * p.alpha);      // filter.py:20-21 / gcn.py:25
         }
         vstore<4>(T + rr * STRIDE + c, acc);
     }
@@ -930,7 +930,7 @@ int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t 
     GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_dropped: invalid activation %d", act);
     GNX_CHECK_ARG(d_D != nullptr, "gnx_spmm_dropped: NULL degree scales");
     GNX_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout rate %g outside [0, 1)", (double)dropout_p);
-    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols, "gnx_spmm_dropped: needs a square graph");
+    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols || g->blk_col_gid != nullptr, "gnx_spmm_dropped: needs a square graph or a vertex block (gnx_graph_set_block)");
     if (g->has_dups) {   // per-entry dropout of duplicated COO entries needs the entry lists: use gnx_graph_normalize + gnx_spmm
         set_error("gnx_spmm_dropped: the graph holds duplicate COO entries");
         return GNX_ERR_UNSUPPORTED;
@@ -948,6 +948,7 @@ int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t 
     p.fuse.thr = (uint32_t)((double)dropout_p * 16777216.0);
     p.fuse.scale = 1.0f / (1.0f - dropout_p);
     p.fuse.transposed = transposed ? 1 : 0;
+    p.fuse.row0_key = g->blk_row0_global; p.fuse.row0_D = g->blk_row0_buf; p.fuse.gid = g->blk_col_gid;
     return launch_spmm(g, transposed ? g->t : g->a, p, s);
 }
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "gnx_graph_normalize": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "gnx_graph_normalize_t": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "gnx_graph_set_dropout_counter": (c_int, [c_void_p, c_void_p]),
+    "gnx_graph_set_block": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gnx_graph_colsum": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "gnx_graph_colsum_streams": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_int, c_void_p, c_void_p]),
     "gnx_degree_scale": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p]),

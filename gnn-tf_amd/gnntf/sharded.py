@@ -96,6 +96,35 @@ class NativeBackend:
     def gather_rows(self, X, idx):
         return sparse.gather_rows(X, idx)
 
+    # ---- training with edge dropout on a vertex block (raw values; weights made inside the kernels) ----------
+    def set_block(self, graph, row0_global, row0_buf, col_gid):
+        """Dropout draws of this block are keyed by GLOBAL (row, col) from now on (gnx_graph_set_block)."""
+        with nat.on_device(graph.device):
+            nat.check(nat.lib().gnx_graph_set_block(graph.handle, int(row0_global), int(row0_buf), nat.ptr(col_gid),
+                                                    nat.current_stream()))
+
+    def colsum_streams(self, graph, p, seed, first_stream, n_streams):
+        """[n_streams, n_cols]: this block's PARTIAL column sums of the dropped raw values, one row per dropout stream."""
+        out = torch.empty((n_streams, graph.n_cols), dtype=torch.float32, device=graph.device)
+        with nat.on_device(graph.device):
+            nat.check(nat.lib().gnx_graph_colsum_streams(graph.handle, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                         int(first_stream) & 0xFFFFFFFFFFFFFFFF, int(n_streams), nat.ptr(out),
+                                                         nat.current_stream()))
+        return out
+
+    def spmm_dropped(self, graph, D, p, seed, stream_id, transposed, X, H0, beta, alpha, out):
+        """out = beta * (A_k X) + alpha * H0 (or A_k^T X) with A_k = the dropped + re-normalised block of dropout stream
+        ``stream_id``; D: the degree scales of every column of the block for that stream."""
+        adj = sparse.DroppedAdjacency(graph, p, seed, stream_id, D=D)
+        sparse._launch(adj, X, H0, beta, alpha, nat.ACT_NONE, transposed=bool(transposed), out=out)
+
+    def spmm_t_mix(self, graph, X, H0, beta, alpha, out):
+        """out = beta * (A^T X) + alpha * H0 over the graph's own (raw) values."""
+        adj = getattr(graph, "_plain_adjacency", None)
+        if adj is None:
+            adj = graph._plain_adjacency = sparse.Adjacency(graph, None)         # keeps the transposed-order values
+        sparse._launch(adj, X, H0, beta, alpha, nat.ACT_NONE, transposed=True, out=out)
+
 
 class Comm:
     """The ranks that share one vertex partition (a torch.distributed group, or a single process).
@@ -327,7 +356,7 @@ class ShardedGraph:
     """This rank's block of a symmetrically normalised, vertex-partitioned square graph."""
 
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
-                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False):
+                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
         (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.  Collective: every rank of the
         vertex partition (``comm`` / ``group``) must call it with the same options.
@@ -337,9 +366,17 @@ class ShardedGraph:
         ``keep_entries``: keep (global row, global col, normalised value, pushed?) of this rank's entries in
         ``self.entries`` (tests).  ``relabel`` (single vertex block only): store the shard with its vertices relabelled in stable order of
         descending entry count -- a legal preprocessing step that makes the sub-wave kernels
-        5-20 % faster; propagate() permutes H0 on the way in and the result on the way out."""
+        5-20 % faster; propagate() permutes H0 on the way in and the result on the way out.
+        ``edge_dropout``: build the block for TRAINING with per-iteration edge dropout (layered.py:47-50 + gnn.py:41-42):
+        raw values (``normalized`` is ignored -- every iteration re-normalises its own dropped entries), classic halo, whole
+        rows; use dropped_scales / propagate_dropped / propagate_dropped_backward instead of propagate()."""
         if cover not in ("cover", "pull"):
             raise Exception("ShardedGraph: cover must be 'cover' or 'pull'")
+        self.edge_dropout = bool(edge_dropout)
+        if self.edge_dropout:
+            normalized, cover, split_rows, relabel = "none", "pull", False, False
+            if int(bounds[-1]) >= 2 ** 31:
+                raise Exception("ShardedGraph: edge dropout across blocks keys its draws by int32 vertex ids")
         self.backend = backend if backend is not None else NativeBackend()
         self.comm = comm if comm is not None else Comm(group=group)
         self.group = self.comm.group
@@ -376,6 +413,8 @@ class ShardedGraph:
         del g0, raw
         self.row_order = None
         self.nnz_local = int(colidx.numel())
+        if self.edge_dropout and self.nnz_local != int(idx_global.shape[0]):
+            raise Exception("ShardedGraph: edge dropout across blocks needs a COO without duplicate entries")
         t = torch.tensor([self.nnz_local], dtype=torch.int64, device=dev)
         self.comm.all_reduce(t)
         self.nnz_global = int(t.item())
@@ -516,6 +555,12 @@ class ShardedGraph:
         else:
             self.graph = be.graph_from_coo(torch.stack([m_rows, m_cols], 1), m_vals, (n_local, self.n_buf))
             self.graph_int, self.rows_bnd, self.rows_int = None, None, None
+        if self.edge_dropout:                                  # dropout draws keyed by the GLOBAL (row, col) of every entry
+            gid = torch.empty(self.n_buf, dtype=torch.int32, device=dev)
+            gid[halo_col] = halo.to(torch.int32)
+            gid[n_before:n_before + n_local] = torch.arange(lo, lo + n_local, dtype=torch.int32, device=dev)
+            self.col_gid = gid
+            be.set_block(self.graph, lo, n_before, gid)
         self.stats = dict(pull_rows=sum(self.pull_counts), push_rows=sum(self.push_counts), pull_only_rows=n_pull_only,
                           send_rows=self.n_send, interior_rows=n_local - n_bnd, boundary_rows=n_bnd, local_rows=n_local)
 
@@ -614,6 +659,105 @@ class ShardedGraph:
             src = dst
         return src
 
+    # ---- training with edge dropout (layered.py:47-50 + gnn.py:41-42 in every iteration) --------------------------
+    # Iteration k of a training forward uses A_k = D_k^-1/2 drop_k(A) D_k^-1/2 with D_k the COLUMN sums of the dropped values.
+    # The draw of entry (i, j) is keyed by (seed, stream, global i, global j): the masks -- and with them the logits -- do not
+    # depend on the partition.  A block holds the raw values of its rows; the weights are made inside the
+    # SpMM (gnx_spmm_dropped).  Column sums and the backward need the halo exchange run BACKWARDS: what a rank computed for
+    # the columns of its halo goes back to their owners, who add it up (the transposed send graph does the adding).
+    def _need_dropout_block(self):
+        if not self.edge_dropout:
+            raise Exception("ShardedGraph: build the block with edge_dropout=True for training with edge dropout")
+
+    def _exchange_back(self, full, back):
+        """The regions of ``full`` go back to their owners; ``back`` [n_send, C] receives what the peers hold for the rows this
+        rank sends them."""
+        sends = [full[a:b] if b > a else None for a, b in self.recv_slices]
+        recvs = [back[a:b] if b > a else None for a, b in self.send_slices]
+        self.comm.exchange(sends, recvs)
+
+    def _pull(self, buf, send):
+        """Fills the regions of ``buf`` from the peers' local rows (one pack launch + one pairwise exchange)."""
+        if self.send_graph is not None:
+            self.backend.spmm_plain(self.send_graph, self.local_view(buf), send[:self.n_send])
+        sends = [send[a:b] if b > a else None for a, b in self.send_slices]
+        recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
+        self.comm.exchange(sends, recvs)
+
+    def _add_back(self, full, back, out):
+        """out = the local rows of ``full`` + what the peers computed for them (``back``, summed by the transposed send graph:
+        a fixed order, whatever the number of peers)."""
+        if self.send_graph is not None:
+            self.backend.spmm_t_mix(self.send_graph, back[:self.n_send], self.local_view(full), 1.0, 1.0, out)
+        else:
+            out.copy_(self.local_view(full))
+
+    def dropped_scales(self, p, seed, first_stream, iterations):
+        """[iterations, n_buf]: divide_no_nan(1, sqrt(GLOBAL column sums of the dropped values)) (gnn.py:41) of the dropout
+        streams first_stream .. first_stream + iterations - 1, for every column of this block's buffer.  Collective."""
+        self._need_dropout_block()
+        be, K = self.backend, int(iterations)
+        part = be.colsum_streams(self.graph, p, seed, first_stream, K)
+        if self.world == 1:
+            return be.degree_scale(part)
+        dev = self.device
+        full = part.t().contiguous()                                            # [n_buf, K]: one "feature row" per column
+        back = torch.zeros((max(self.n_send, 1), K), dtype=torch.float32, device=dev)
+        self._exchange_back(full, back)
+        total = torch.empty((self.n_local, K), dtype=torch.float32, device=dev)
+        self._add_back(full, back, total)
+        be.degree_scale(total)
+        self.local_view(full).copy_(total)
+        self._pull(full, back)                                                   # the owners' scales into the halo columns
+        return full.t().contiguous()
+
+    def propagate_dropped(self, H0, a, iterations, p, seed, first_stream, scales):
+        """The K training-mode iterations over this rank's rows: H <- (1-a) A_k H + a H0, k = 0 .. K-1."""
+        self._need_dropout_block()
+        be = self.backend
+        H0 = H0.to(torch.float32).contiguous()
+        C, dev = H0.shape[1], H0.device
+        if self.world == 1:
+            H = H0
+            for k in range(iterations):
+                out = torch.empty_like(H0)
+                be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, False, H, H0, 1.0 - a, a, out)
+                H = out
+            return H
+        bufs = [torch.zeros((self.n_buf, C), dtype=torch.float32, device=dev) for _ in range(2)]
+        send = torch.zeros((max(self.n_send, 1), C), dtype=torch.float32, device=dev)
+        self.local_view(bufs[0]).copy_(H0)
+        for k in range(iterations):
+            src, dst = bufs[k % 2], bufs[1 - k % 2]
+            self._pull(src, send)
+            be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, False, src, H0, 1.0 - a, a, self.local_view(dst))
+        return self.local_view(bufs[iterations % 2]).clone()
+
+    def propagate_dropped_backward(self, g, a, iterations, p, seed, first_stream, scales):
+        """dH0 of propagate_dropped for the output gradient g (this rank's rows): g_k = (1-a) A_k^T g_{k+1},
+        dH0 = g_0 + a sum_k g_{k+1}.  A_k^T reaches the halo columns too: those rows go back to their owners."""
+        self._need_dropout_block()
+        be = self.backend
+        G = g.to(torch.float32).contiguous()
+        C, dev = G.shape[1], G.device
+        gH0 = torch.zeros_like(G)
+        if self.world > 1:
+            full = torch.empty((self.n_buf, C), dtype=torch.float32, device=dev)
+            back = torch.zeros((max(self.n_send, 1), C), dtype=torch.float32, device=dev)
+        for k in range(iterations - 1, -1, -1):
+            gH0.add_(G, alpha=a)
+            if self.world == 1:
+                nxt = torch.empty_like(G)
+                be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, True, G, None, 1.0 - a, 0.0, nxt)
+            else:
+                be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, True, G, None, 1.0 - a, 0.0, full)
+                self._exchange_back(full, back)
+                nxt = torch.empty_like(G)
+                self._add_back(full, back, nxt)
+            G = nxt
+        gH0.add_(G)
+        return gH0
+
     # ---- measurements for bench.py ------------------------------------------------------------------------
     def time_exchange(self, state, repeats=3):
         """Seconds of one bare exchange of every chunk's outgoing rows (no compute beside it), max over ranks."""
@@ -690,6 +834,24 @@ class _BlockLoop(torch.autograd.Function):
         return ctx.layer._propagate("backward", g.contiguous()), None
 
 
+class _BlockDroppedLoop(torch.autograd.Function):
+    """The K training-mode iterations with per-iteration edge dropout over a vertex block.  Linear in H0, and every A_k is
+    regenerated from the counter RNG, so nothing but the degree scales (K x n_buf floats) is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, H0, layer, seed, first):
+        sg, p, K = layer.dropout_graph, layer.graph_dropout, layer.iterations
+        scales = sg.dropped_scales(p, seed, first, K)
+        ctx.layer, ctx.seed, ctx.first, ctx.scales = layer, seed, first, scales
+        return sg.propagate_dropped(H0.detach(), layer.restart_probability, K, p, seed, first, scales)
+
+    @staticmethod
+    def backward(ctx, g):
+        layer = ctx.layer
+        return layer.dropout_graph.propagate_dropped_backward(g.contiguous(), layer.restart_probability, layer.iterations,
+                                                              layer.graph_dropout, ctx.seed, ctx.first, ctx.scales), None, None, None
+
+
 class ShardedPPRLoop(Layer):
     """The K PPRIteration layers of APPNP (filter.py:34-35) for a model that holds ONE vertex block of the graph: every rank
     builds the same layer stack over the rows of its block (the Dense layers before it act row by row, so they need no
@@ -703,14 +865,21 @@ class ShardedPPRLoop(Layer):
 
     Training works too when the adjacency is symmetric and constant (an undirected graph, no edge dropout): the backward of
     the loop is then the loop itself applied to the gradient (see _BlockLoop), the parameter gradients of the row-wise layers
-    are summed over the ranks by ``SummedGradients`` and the task is a ``BlockNodeClassification``."""
+    are summed over the ranks by ``SummedGradients`` and the task is a ``BlockNodeClassification``.
+
+    ``graph_dropout`` > 0 (APPNP's default is 0.5, filter.py:8) needs ``dropout_graph``: the same rows built with
+    ``ShardedGraph(..., edge_dropout=True)``.  In training mode every iteration then drops and re-normalises its edges exactly as
+    the one-GPU PPRLoop does -- same masks, whatever the partition -- and the backward sends the halo rows of A_k^T g back to
+    their owners; directed graphs are fine on this path.  Every rank must have called gnntf.set_seed with the same seed."""
 
     def __build__(self, architecture, H0: Layer, graph: "ShardedGraph", restart_probability: float = 0.1, iterations: int = 10,
-                  symmetric: bool = True):
+                  symmetric: bool = True, graph_dropout: float = 0.0, dropout_graph: "ShardedGraph" = None):
         if architecture.top_shape()[0] != graph.n_local:
             raise Exception("ShardedPPRLoop: the architecture must hold this rank's %d rows" % graph.n_local)
+        if graph_dropout != 0 and (dropout_graph is None or not dropout_graph.edge_dropout or dropout_graph.n_local != graph.n_local):
+            raise Exception("ShardedPPRLoop: graph_dropout needs dropout_graph = ShardedGraph(same rows, edge_dropout=True)")
         self.H0, self.graph, self.restart_probability, self.iterations = H0, graph, restart_probability, iterations
-        self.symmetric = symmetric
+        self.symmetric, self.graph_dropout, self.dropout_graph = symmetric, graph_dropout, dropout_graph
         self._states = dict()
         return architecture.top_shape()
 
@@ -727,6 +896,9 @@ class ShardedPPRLoop(Layer):
 
     def __forward__(self, architecture, features):
         H0 = self.H0.value
+        if self.graph_dropout != 0 and architecture.is_training():
+            seed, first = architecture._next_mask_stream(self.iterations)
+            return _BlockDroppedLoop.apply(H0, self, seed, first)
         if torch.is_grad_enabled() and H0.requires_grad:
             if not self.symmetric:
                 raise Exception("ShardedPPRLoop: gradients need a symmetric adjacency (the backward reuses the forward propagation)")

@@ -100,6 +100,16 @@ int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropou
  * captured launches stay fixed, the step's last node advances the counter (layered.py:47-50 draws new masks per call). */
 int gnx_graph_set_dropout_counter(gnx_graph_t g, const uint64_t *d_counter);
 
+/* gnx_graph_set_block: declares the handle to be ONE VERTEX BLOCK of a larger square graph (multi-GPU training with edge
+ * dropout): its row r is global vertex row0_global + r, its column c is global vertex d_col_gid[c]
+ * (int32 [n_cols], copied), and local row r is column row0_buf + r of the block's own column space (the [regions | local rows |
+ * regions] buffer of gnx_halo_plan_layout).  From then on the dropout draws of gnx_graph_colsum(_streams) /
+ * gnx_graph_scale_values / gnx_spmm_dropped are keyed by the GLOBAL (row, col) -- the masks equal the one-GPU masks whatever
+ * the partition -- and gnx_spmm_dropped accepts the rectangular block: d_D is then [n_cols] (scales of every buffer column),
+ * row r's own scale being d_D[row0_buf + r].  gnx_graph_colsum gives the block's PARTIAL column sums; the caller adds the
+ * blocks up (halo columns go back to their owners) before gnx_degree_scale.  d_col_gid == NULL undoes the declaration. */
+int gnx_graph_set_block(gnx_graph_t g, int64_t row0_global, int64_t row0_buf, const int32_t *d_col_gid, void *stream);
+
 /* gnx_graph_normalize_t: the same normalisation, but the values are written in the order of the TRANSPOSED
  * structure (the order gnx_spmm_tv consumes).  The backward pass of a training step only needs A_hat^T, so it
  * regenerates the iteration's dropped adjacency straight into this order instead of permuting a CSR-order
@@ -167,7 +177,8 @@ int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, co
  * gnx_graph_normalize(g, GNX_NORM_SYMMETRIC, GNX_EYE_NONE, dropout_p, seed, stream_id, ...) followed by gnx_spmm.
  * d_D [n]: the degree scales of that iteration = gnx_graph_colsum(g, dropout_p, seed, stream_id, d_D) then
  * gnx_degree_scale(d_D, n, GNX_NORM_SYMMETRIC, 0).  Saves the nnz-sized value array and the pass that writes it
- * (layered.py:47-50 + gnn.py:41-42 happen in the SpMM's value fetch).  Square graphs; GNX_ERR_UNSUPPORTED when the COO held
+ * (layered.py:47-50 + gnn.py:41-42 happen in the SpMM's value fetch).  Square graphs or vertex blocks (gnx_graph_set_block);
+ * GNX_ERR_UNSUPPORTED when the COO held
  * duplicate entries (their per-entry dropout needs the entry lists: use gnx_graph_normalize). */
 int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int transposed,
                      const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha,

@@ -82,12 +82,49 @@ class OracleBackend:
     def gather_rows(self, X, idx):
         return X[idx].contiguous()
 
+    # ---- edge dropout on a vertex block: the arithmetic of gnx_graph_colsum_streams / gnx_spmm_dropped, in numpy ----
+    def set_block(self, g, row0_global, row0_buf, col_gid):
+        g.row0_global, g.row0_buf, g.col_gid = int(row0_global), int(row0_buf), col_gid.numpy().astype(np.int64)
 
-def train_on_blocks(rank, world, dev, backend):
+    def _dropped_raw(self, g, p, seed, stream):
+        rows = np.repeat(np.arange(g.n_rows), np.diff(g.rowptr))
+        gid = getattr(g, "col_gid", None)
+        krow = rows + getattr(g, "row0_global", 0)
+        kcol = g.colidx.astype(np.int64) if gid is None else gid[g.colidx]
+        keep = orc.hash_u24(seed, stream, krow, kcol, np.zeros(len(rows), dtype=np.int64)) >= orc.dropout_threshold(p)
+        scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+        return rows, np.where(keep, g.vals * scale, np.float32(0)).astype(np.float32)
+
+    def colsum_streams(self, g, p, seed, first_stream, n_streams):
+        out = np.zeros((n_streams, g.n_cols), dtype=np.float32)
+        for k in range(n_streams):
+            _, v = self._dropped_raw(g, p, seed, first_stream + k)
+            np.add.at(out[k], g.colidx, v)
+        return torch.from_numpy(out)
+
+    def spmm_dropped(self, g, D, p, seed, stream_id, transposed, X, H0, beta, alpha, out):
+        rows, v = self._dropped_raw(g, p, seed, stream_id)
+        D = D.numpy()
+        w = (D[rows + getattr(g, "row0_buf", 0)] * v) * D[g.colidx]
+        m = sp.csr_matrix((w, g.colidx, g.rowptr), shape=g.shape)
+        prod = ((m.T if transposed else m) @ X.numpy()) * np.float32(beta)
+        if H0 is not None:
+            prod = prod + H0.numpy() * np.float32(alpha)
+        out.copy_(torch.from_numpy(np.ascontiguousarray(prod, dtype=np.float32)))
+
+    def spmm_t_mix(self, g, X, H0, beta, alpha, out):
+        m = sp.csr_matrix((g.vals, g.colidx, g.rowptr), shape=g.shape)
+        out.copy_(torch.from_numpy(np.ascontiguousarray((m.T @ X.numpy()) * np.float32(beta) + H0.numpy() * np.float32(alpha), dtype=np.float32)))
+
+
+def train_on_blocks(rank, world, dev, backend, graph_dropout=0.0):
     """architecture.train() with every rank holding ONE vertex block (ShardedPPRLoop + SummedGradients +
-    BlockNodeClassification) against single-process dense float64 training of the same model: same parameters afterwards."""
+    BlockNodeClassification) against single-process dense float64 training of the same model: same parameters afterwards.
+    graph_dropout > 0: every training forward drops + re-normalises the edges per iteration (masks by global ids, streams
+    numbered as Layered._next_mask_stream does); the reference rebuilds the same dropped adjacencies from the oracle."""
     import gnntf
     gnntf.set_default_device(dev)
+    gnntf.set_seed(33)
     n, F, hidden, classes, K, a, epochs = 600, 10, 8, 4, 6, 0.1, 8
     coo, vals, shape = graphs.rmat_symmetric_coo(n, 5000, seed=8)
     rng = np.random.default_rng(8)
@@ -101,7 +138,12 @@ def train_on_blocks(rank, world, dev, backend):
     model = gnntf.Trainable(torch.from_numpy(X[lo:hi]).to(dev))
     model.add(gnntf.Dense(hidden, activation=gnntf.relu))
     head = model.add(gnntf.Dense(classes, regularize=False))
-    model.add(sharded.ShardedPPRLoop(head, sg, a, K))
+    if graph_dropout:
+        dg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend,
+                                  edge_dropout=True)
+        model.add(sharded.ShardedPPRLoop(head, sg, a, K, graph_dropout=graph_dropout, dropout_graph=dg))
+    else:
+        model.add(sharded.ShardedPPRLoop(head, sg, a, K))
     local = lambda ids: ids[(ids >= lo) & (ids < hi)]
     tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
     torch.manual_seed(21)                                          # reset() draws the same initial weights on every rank
@@ -120,16 +162,20 @@ def train_on_blocks(rank, world, dev, backend):
     Xt, yt = torch.from_numpy(X.astype(np.float64)), torch.from_numpy(labels)
     opt = torch.optim.Adam([W1, b1, W2, b2], lr=0.01, eps=1e-7)
 
-    def forward():
+    def dropped(stream):
+        di, dv = orc.get_adjacency(coo, vals, shape, graph_dropout=graph_dropout, training=True, seed=33, stream=stream, dtype=np.float64)
+        return torch.from_numpy(orc.to_dense(di, dv, shape, dtype=np.float64))
+
+    def forward(first=None):
         H0 = torch.relu(Xt @ W1 + b1) @ W2 + b2
         H = H0
-        for _ in range(K):
-            H = (A @ H) * (1 - a) + H0 * a
+        for k in range(K):
+            H = ((A if first is None else dropped(first + k)) @ H) * (1 - a) + H0 * a
         return H
     best, best_params = float("inf"), None
-    for _ in range(epochs):
+    for epoch in range(epochs):
         opt.zero_grad()
-        loss = torch.nn.functional.cross_entropy(forward()[train_ids], yt[train_ids]) + 5e-4 * ((W1 ** 2).sum() + (b1 ** 2).sum()) / 2
+        loss = torch.nn.functional.cross_entropy(forward(epoch * K if graph_dropout else None)[train_ids], yt[train_ids]) + 5e-4 * ((W1 ** 2).sum() + (b1 ** 2).sum()) / 2
         loss.backward()
         opt.step()
         with torch.no_grad():
@@ -146,7 +192,67 @@ def train_on_blocks(rank, world, dev, backend):
     assert abs(accuracy - want_acc) < 0.02, (accuracy, want_acc)
     gnntf.set_default_device(None)
     if rank == 0:
-        print("OK train world", world, "valid accuracy", round(accuracy, 3))
+        print("OK train_dropout" if graph_dropout else "OK train", "world", world, "valid accuracy", round(accuracy, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def dropout_on_blocks(rank, world, dev, backend, directed):
+    """Training-mode propagation with per-iteration edge dropout on vertex blocks: the masks are keyed by global (row, col),
+    so forward and backward must equal the single-process oracle with the same seed, whatever the partition."""
+    n, C, K, a, p, seed, first = 700, 9, 5, 0.1, 0.5, 12345, 7
+    if directed:
+        rng = np.random.default_rng(11)
+        key = np.unique(rng.integers(n, size=6000) * n + (rng.random(6000) ** 3 * n).astype(np.int64))
+        coo = np.stack([key // n, key % n], 1)
+        vals = rng.random(len(key)).astype(np.float32) + 0.5
+    else:
+        coo, vals, _ = graphs.rmat_symmetric_coo(n, 7000, seed=5)
+    rng = np.random.default_rng(2)
+    H0_full = rng.uniform(-1, 1, size=(n, C)).astype(np.float32)
+    G_full = rng.uniform(-1, 1, size=(n, C)).astype(np.float32)
+    bounds = sharded.uniform_bounds(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
+    sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend,
+                              edge_dropout=True)
+    assert sg.cover == "pull" and (world == 1 or not sg.split_rows)
+    scales = sg.dropped_scales(p, seed, first, K)
+    H0 = torch.from_numpy(H0_full[lo:hi].copy()).to(dev)
+    out = sg.propagate_dropped(H0, a, K, p, seed, first, scales)
+    gH0 = sg.propagate_dropped_backward(torch.from_numpy(G_full[lo:hi].copy()).to(dev), a, K, p, seed, first, scales)
+    # ---- single process, the oracle's get_adjacency in training mode with the same (seed, stream) per iteration ---------
+    adjs = [orc.get_adjacency(coo, vals, (n, n), graph_dropout=p, training=True, seed=seed, stream=first + k) for k in range(K)]
+    H = H0_full.astype(np.float64)
+    for ai, av in adjs:
+        H = orc.ppr_iteration(ai, av.astype(np.float64), (n, n), H, H0_full.astype(np.float64), a)
+    g, want_g = G_full.astype(np.float64), np.zeros((n, C))
+    for ai, av in reversed(adjs):
+        want_g += a * g
+        g = (1 - a) * (sp.csr_matrix((av.astype(np.float64), (ai[:, 0], ai[:, 1])), shape=(n, n)).T @ g)
+    want_g += g
+    dropped = [float((av == 0).mean()) for _, av in adjs]
+    assert all(0.4 < d < 0.6 for d in dropped), dropped            # the masks really drop about half the entries
+    if world > 1:                                                  # ... and the degree scales are the global ones
+        colsum = np.zeros(n, dtype=np.float64)
+        ai, av = orc.get_adjacency(coo, vals, (n, n), graph_dropout=p, normalized="none", training=True, seed=seed, stream=first)
+        np.add.at(colsum, ai[:, 1], av)
+        want_D = np.where(colsum > 0, 1.0 / np.sqrt(np.maximum(colsum, 1e-30)), 0.0)
+        np.testing.assert_allclose(scales[0].cpu().numpy(), want_D[sg.col_gid.cpu().numpy()], rtol=2e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), H[lo:hi], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(gH0.cpu().numpy(), want_g[lo:hi], rtol=2e-4, atol=2e-5)
+    if dev.type == "cuda":                                         # and against ONE GPU holding the whole graph (same masks)
+        import gnntf
+        from gnntf import sparse
+        whole = gnntf.DeviceGraph(gnntf.SparseCOO(coo, vals, (n, n)), device=dev)
+        D1 = sparse.dropped_degree_scales(whole, p, seed, first, K)
+        Hf = torch.from_numpy(H0_full).to(dev).requires_grad_(True)
+        single = sparse.ppr_loop(lambda k, bwd=False: sparse.dropped_adjacency(whole, p, seed, first + k, D=D1[k]), Hf, a, K)
+        single.backward(torch.from_numpy(G_full).to(dev))
+        np.testing.assert_allclose(out.cpu().numpy(), single.detach().cpu().numpy()[lo:hi], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(gH0.cpu().numpy(), Hf.grad.cpu().numpy()[lo:hi], rtol=1e-5, atol=1e-6)
+    if rank == 0:
+        print("OK dropout_directed" if directed else "OK dropout", "world", world, "dropped", [round(d, 3) for d in dropped])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -158,6 +264,13 @@ def main():
     if mode == "train":
         on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
         return train_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())
+    if mode == "train_dropout":
+        on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
+        return train_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend(), 0.5)
+    if mode in ("dropout", "dropout_directed"):
+        on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
+        return dropout_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend(),
+                                 mode == "dropout_directed")
     on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"          # GPU box: every rank shares cuda:0, libgnx.so backend
     opts = (sys.argv[3] if len(sys.argv) > 3 else "cover,split,2").split(",")
     options = dict(cover=opts[0], split_rows=opts[1] == "split", chunks=int(opts[2]), keep_entries=True)

@@ -64,6 +64,21 @@ def test_training_on_vertex_blocks(world):
     launch(world, "train")
 
 
+@pytest.mark.parametrize("world,mode", [(1, "dropout"), (2, "dropout"), (3, "dropout"), (4, "dropout"), (3, "dropout_directed")])
+def test_edge_dropout_on_vertex_blocks(world, mode):
+    """Training-mode propagation with per-iteration edge dropout + re-normalisation across blocks (last bullet):
+    masks keyed by global (row, col), global column sums through the reversed halo exchange, backward through A_k^T with the
+    halo rows of the gradient returned to their owners -- forward and dH0 equal the single-process oracle for every world size."""
+    launch(world, mode)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_training_with_edge_dropout_on_vertex_blocks(world):
+    """architecture.train() over vertex blocks with APPNP's default graph_dropout = 0.5: same parameters as single-process
+    dense float64 training that rebuilds every iteration's dropped adjacency from the oracle."""
+    launch(world, "train_dropout")
+
+
 def test_choose_grid_and_columns():
     """Planning helpers: the grid cost model takes a MEASURED link rate (no built-in default), and the column
     chunks are whole 128-byte lines wherever the width allows."""
@@ -103,7 +118,8 @@ def test_cover_push_mask_properties():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,options", [("slices", "cover,split,2"), ("slices", "pull,whole,1"), ("blocks", "cover,split,2"),
-                                          ("rmat", "cover,whole,2"), ("grid1x2", "cover,split,2"), ("train", "cover,split,2")])
+                                          ("rmat", "cover,whole,2"), ("grid1x2", "cover,split,2"), ("train", "cover,split,2"),
+                                          ("dropout", "-"), ("dropout_directed", "-"), ("train_dropout", "-")])
 def test_sharded_native_backend_two_ranks_one_gpu(mode, options):
     """The libgnx.so backend on real shards (rectangular CSR over [regions | local | regions], interior / boundary
     handles with row maps, the send CSR, exchange on its own stream): two ranks share cuda:0 and exchange over gloo
