@@ -21,6 +21,7 @@
 //     (fixed order: results are bitwise reproducible, no float atomics).  Chunks are processed in
 //     column-window order (Csr::chunk_order) so the hub rows they share stay in L2 / Infinity Cache.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "gnx_internal.h"
 
@@ -692,6 +693,39 @@ __global__ __launch_bounds__(256) void k_stream_copy(const f32x4 *__restrict__ s
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
+// out = sum_j coef[j] * src[j], elementwise over up to 16 equally long arrays, summed in index order (fixed rounding): the
+// backward of the K-iteration loop ends with dH0 = g_0 + a (g_1 + ... + g_K) -- one pass over the K + 1 gradients it kept
+// instead of a read-modify-write of dH0 after every iteration
+constexpr int LINCOMB_MAX = 16;
+struct LinComb {
+    const float *src[LINCOMB_MAX];
+    float coef[LINCOMB_MAX];
+    int k;
+};
+__global__ __launch_bounds__(256) void k_lincomb(LinComb a, int64_t n4, int64_t n, float *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 v[LINCOMB_MAX];
+#pragma unroll
+        for (int j = 0; j < LINCOMB_MAX; ++j)
+            if (j < a.k) v[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(a.src[j]) + i);
+        f32x4 acc = v[0] * a.coef[0];
+#pragma unroll
+        for (int j = 1; j < LINCOMB_MAX; ++j)
+            if (j < a.k) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v[j][c], a.coef[j], acc[c]);
+            }
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4 *>(out) + i);
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < n - 4 * n4) {           // the last n % 4 elements
+        const int64_t i = 4 * n4 + threadIdx.x;
+        float acc = a.src[0][i] * a.coef[0];
+        for (int j = 1; j < a.k; ++j) acc = fmaf(a.src[j][i], a.coef[j], acc);
+        out[i] = acc;
+    }
+}
+
 // read-only counterpart: every lane keeps four 16-byte loads in flight and folds them into one float per block -- the SpMM is
 // almost all reads, so this is the closer yardstick for it
 __global__ __launch_bounds__(256) void k_stream_read(const f32x4 *__restrict__ src, int64_t n4, float *__restrict__ sink) {
@@ -1092,6 +1126,24 @@ int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *st
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_dst && aligned(d_src, 16) && aligned(d_dst, 16), "gnx_stream_copy: NULL or unaligned pointer");
     hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst, n_floats / 4);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
+int gnx_linear_combination(int k, const float *const *d_src, const float *coef, int64_t n, float *d_out, void *stream) {
+    GNX_CHECK_ARG(k >= 1 && k <= LINCOMB_MAX, "gnx_linear_combination: 1 to %d terms, got %d", LINCOMB_MAX, k);
+    GNX_CHECK_ARG(n >= 0 && d_src != nullptr && coef != nullptr, "gnx_linear_combination: bad arguments");
+    if (n == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_out != nullptr && aligned(d_out, 16), "gnx_linear_combination: NULL or unaligned output");
+    LinComb a{};
+    a.k = k;
+    for (int j = 0; j < k; ++j) {
+        GNX_CHECK_ARG(d_src[j] != nullptr && aligned(d_src[j], 16), "gnx_linear_combination: term %d is NULL or unaligned", j);
+        a.src[j] = d_src[j]; a.coef[j] = coef[j];
+    }
+    const int64_t n4 = n / 4;
+    const unsigned nb = (unsigned)std::min<int64_t>(std::max<int64_t>((n4 + 255) / 256, 1), 256 * 16);
+    hipLaunchKernelGGL(k_lincomb, dim3(nb), dim3(256), 0, (hipStream_t)stream, a, n4, n, d_out);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }

@@ -68,6 +68,7 @@ SIGNATURES = {
     "gnx_edge_scores": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "gnx_edge_scores_backward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_void_p]),
+    "gnx_linear_combination": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "gnx_stream_read": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "gnx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_graph_last_kernel": (c_char_p, [c_void_p]),

@@ -6,7 +6,7 @@ gnntf/core/gnn/architectures/gcn.py:88).
 """
 from __future__ import annotations
 
-from ctypes import byref, c_int64, c_void_p
+from ctypes import byref, c_float, c_int64, c_void_p
 
 import numpy as np
 import torch
@@ -360,13 +360,42 @@ class _PPRLoop(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        # dH0 = g_0 + a (g_1 + ... + g_K): the gradients of the iterations are KEPT (as many as a tenth of the card's memory
+        # holds, at most 15) and added up by one pass (gnx_linear_combination) instead of a read-modify-write of dH0 per iteration
         g = g.contiguous()
-        gH0 = torch.zeros_like(g)
+        room = int(0.1 * torch.cuda.get_device_properties(g.device).total_memory) // max(g.numel() * 4, 1)
+        limit = max(2, min(LINCOMB_TERMS - 1, room))
+        pending, total = [], None
         for k in range(ctx.K - 1, -1, -1):
-            gH0.add_(g, alpha=ctx.a)
+            pending.append((g, ctx.a))
+            if len(pending) >= limit:
+                total, pending = linear_combination(([(total, 1.0)] if total is not None else []) + pending), []
             g = _launch(ctx.make_adj(k, True), g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
-        gH0.add_(g)
-        return gH0, None, None, None
+        pending.append((g, 1.0))
+        return linear_combination(([(total, 1.0)] if total is not None else []) + pending), None, None, None
+
+
+LINCOMB_TERMS = 16
+
+
+def linear_combination(terms) -> torch.Tensor:
+    """sum_j coef_j * tensor_j for up to 16 equally shaped float32 device tensors, ``terms`` = [(tensor, coef), ...], in ONE pass
+    (gnx_linear_combination; terms are added in list order).  Returns a new tensor."""
+    if not 1 <= len(terms) <= LINCOMB_TERMS:
+        raise Exception("linear_combination: 1 to %d terms" % LINCOMB_TERMS)
+    tensors = [t if t.is_contiguous() else t.contiguous() for t, _ in terms]
+    first = tensors[0]
+    nat.require_cuda(*tensors)
+    for t in tensors:
+        if t.shape != first.shape or t.dtype != torch.float32 or t.device != first.device:
+            raise Exception("linear_combination: the terms must be float32 tensors of one shape on one device")
+    out = torch.empty_like(first)
+    k = len(tensors)
+    ptrs = (c_void_p * k)(*[t.data_ptr() for t in tensors])
+    coefs = (c_float * k)(*[float(c) for _, c in terms])
+    with nat.on_device(first.device):
+        nat.check(nat.lib().gnx_linear_combination(k, ptrs, coefs, first.numel(), nat.ptr(out), nat.current_stream()))
+    return out
 
 
 def ppr_loop(make_adj, H0: torch.Tensor, a: float, iterations: int) -> torch.Tensor:

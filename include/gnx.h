@@ -288,6 +288,11 @@ int gnx_edge_scores_backward(const float *d_F, int64_t ldf, int64_t n_rows, int6
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C,
                     float *d_out, int64_t ldo, void *stream);
 
+/* gnx_linear_combination: d_out[i] = sum_j coef[j] * d_src[j][i] over k <= 16 device arrays of n floats (d_src and coef are HOST
+ * arrays of k entries; terms are added in index order; d_out may be one of the sources).  Ends the backward of the K-iteration
+ * loop -- dH0 = g_0 + a (g_1 + ... + g_K), the adjoint of filter.py:20-21's "+ a * H0" in every iteration -- in one pass. */
+int gnx_linear_combination(int k, const float *const *d_src, const float *coef, int64_t n, float *d_out, void *stream);
+
 /* Measurement aid: a float4 streaming copy d_dst[0..n) = d_src[0..n) (n a multiple of 4, 16-byte aligned pointers).
  * bench.py times it next to the propagation as the measured-peak HBM rate (read + write bytes per second). */
 int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *stream);

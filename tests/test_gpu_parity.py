@@ -695,3 +695,21 @@ def test_full_size_properties(gnntf):
     l = (gnntf.spmm(sym, x).double() * y.double()).sum()
     r = (x.double() * _launch(sym, y, None, 1.0, 0.0, 0, transposed=True).double()).sum()
     assert abs(float(l - r)) <= 1e-6 * abs(float(l))
+
+
+@pytest.mark.parametrize("n,k", [(7, 1), (4096, 3), (100003, 11), (65536 * 9 + 2, 16)])
+def test_linear_combination_one_pass(gnntf, n, k):
+    """gnx_linear_combination (the end of the K-loop backward: dH0 = g_0 + a (g_1 + ... + g_K)): sum of up to 16 scaled arrays,
+    terms added in list order with fmaf -- bit for bit the same chain on the host; lengths that are not multiples of 4."""
+    from gnntf.sparse import linear_combination
+    rng = np.random.default_rng(n + k)
+    arrays = [rng.standard_normal(n).astype(np.float32) for _ in range(k)]
+    coefs = [float(np.float32(c)) for c in rng.uniform(-2, 2, size=k)]
+    got = linear_combination([(dev(x), c) for x, c in zip(arrays, coefs)]).cpu().numpy()
+    want = arrays[0].astype(np.float64) * np.float32(coefs[0])
+    want = want.astype(np.float32)
+    for x, c in zip(arrays[1:], coefs[1:]):
+        want = (x.astype(np.float64) * np.float64(np.float32(c)) + want.astype(np.float64)).astype(np.float32)   # fmaf: one rounding
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)    # (double rounding of the float64 emulation aside, the same bits)
+    with pytest.raises(Exception, match="1 to 16 terms"):
+        linear_combination([(dev(arrays[0]), 1.0)] * 17)
