@@ -300,7 +300,8 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     W, b = torch.randn(256, 64, device=device) / 16, torch.randn(1, 64, device=device)
     with torch.no_grad():
         t_dense = median_ms(lambda: gnntf.dense(X, W, b, relu=True), reps=5, warm=2)
-    mf["dense_10M_x_256_to_64_relu"] = {"ms": t_dense, "TFLOPs": 2.0 * n * 256 * 64 / t_dense / 1e9, "GBs": (n * 256 * 4 + n * 64 * 4) / t_dense / 1e6,
+        t_torch = median_ms(lambda: torch.relu(torch.addmm(b, X, W)), reps=5, warm=2)      # hipBLASLt GEMM + separate bias / relu passes
+    mf["dense_10M_x_256_to_64_relu"] = {"ms": t_dense, "torch_addmm_relu_ms": t_torch, "TFLOPs": 2.0 * n * 256 * 64 / t_dense / 1e9, "GBs": (n * 256 * 4 + n * 64 * 4) / t_dense / 1e6,
                                         "mfma_peak_TFLOPs": 157.3, "what": "gnx_dense, float32 v_mfma_f32_16x16x4_f32; X read once from HBM"}
     del X
     logits = torch.randn(n, 40, device=device)
