@@ -364,6 +364,16 @@ def relaunch_under_torchrun(args):
     raise SystemExit(res.returncode)
 
 
+def note(msg):
+    """Progress line on stderr (rank 0 only; stdout carries nothing but the JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - T_START, msg))
+        sys.stderr.flush()
+
+
+T_START = time.time()
+
+
 def main():
     args = parse()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -407,6 +417,7 @@ def main():
     if not sharded_path:
         g, adj, prep = build_single(args, device)
         n_local, nnz_local, nnz_global = g.n_rows, g.nnz, g.nnz
+        note(f"graph built: {g.n_rows} rows / {g.nnz} entries, prep {prep}")
         gen = torch.Generator(device=device).manual_seed(2)
         H0 = torch.rand(n_local, C, device=device, generator=gen) * 2 - 1       # U(-1, 1), seed 2
         out = torch.empty_like(H0)
@@ -425,6 +436,7 @@ def main():
                                                               cover=args.cover, chunks=args.chunks, split_rows=not args.whole_rows,
                                                               relabel=True)
         n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
+        note(f"vertex blocks built: {pv} x {pf} grid, {n_local} rows / {nnz_local} entries on rank 0, prep {prep}")
         C_local = C // pf                                                       # this rank's feature slice
         gen = torch.Generator(device=device).manual_seed(2 + rank)
         H0 = torch.rand(n_local, C_local, device=device, generator=gen) * 2 - 1
@@ -439,7 +451,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"timing {args.warmup} + {args.steps} steps")
     elapsed, step_ms = timed_steps(step, args.steps, args.warmup, barrier)
+    note(f"steps done: {elapsed / args.steps * 1e3:.1f} ms per step on this rank")
     if sharded_path:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,7 +469,10 @@ def main():
     # N > 1, second field (never the headline): the SAME graph replicated on every rank, each rank propagating C / N of the feature
     # columns -- no exchange at all, graph memory and prep grow with N.  Tells how far the vertex blocks are from a link-free bound.
     alt = None
+    if world > 1:
+        note(f"exchange alone {halo['exchange_ms_alone']:.2f} ms, kernels alone {halo['compute_ms_alone']:.2f} ms per iteration")
     if world > 1 and not args.no_alt_grid and not args.grid and C % world == 0:
+        note("second field: the whole graph on every rank, C / N columns each")
         kernel_blocks = sg.graph.last_kernel()
         del state, sg, H0
         torch.cuda.empty_cache()
@@ -477,6 +494,7 @@ def main():
                "note": "graph replicated on every rank (memory and prep x N), no data-path communication; reported beside the headline "
                        "vertex-block grid, never instead of it"}
         del g2, adj2, H2, out2, work2
+        note(f"feature slices: {alt['ms_per_step']:.1f} ms per step")
     else:
         kernel_blocks = sg.graph.last_kernel() if sharded_path else None
 
@@ -505,12 +523,14 @@ def main():
             "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:
+            note("CPU baseline (oracle port, bounded sample)")
             result["cpu_baseline"] = cpu_baseline(g, H0, args)
         else:
             result["cpu_baseline"] = None
         if not sharded_path and not args.no_secondary:
             del g, adj, H0, out, work
             torch.cuda.empty_cache()
+            note("secondary workloads")
             result["secondary"] = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4")
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if sharded_path:
