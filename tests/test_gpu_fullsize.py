@@ -95,3 +95,82 @@ def test_config5_full_size_eigenvector(gnntf):
     eigenvector_check(gnntf, g, adj, 128)
     del g, adj
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("world,cover,n,entries,C", [(8, "cover", 8_000_000, 100_000_000, 128), (4, "pull", 2_000_000, 24_000_000, 64),
+                                                     (3, "cover", 1_000_003, 12_000_000, 40)])
+def test_vertex_blocks_of_one_graph_match_one_gpu(gnntf, world, cover, n, entries, C):
+    """SURVEY 8(e) parity check at a realistic size: ALL P vertex blocks of one R-MAT graph live on this one GPU (the ranks are
+    threads of this process, tests/thread_comm.py), each with its real halo plan, send CSR, interior / boundary handles and
+    column chunks; the K = 10 propagation over the blocks must equal gnx_appnp_propagate over the whole graph."""
+    from gnntf import sharded
+    from thread_comm import run_ranks
+    device = torch.device("cuda:0")
+    u, w = sharded.rmat_relabelled_pairs(n, entries // 2, seed=1, device=device)
+    H0 = torch.rand(n, C, device=device, generator=torch.Generator(device=device).manual_seed(2)) * 2 - 1
+    bounds = sharded.uniform_bounds(n, world)
+
+    def rank_body(comm):
+        lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+        mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
+        idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
+        sg = sharded.ShardedGraph(idx, torch.ones(idx.shape[0], device=device), bounds, comm=comm, cover=cover, chunks=2)
+        state = sg.make_state(H0[lo:hi])
+        out = sg.propagate(state, 0.1, 10).clone()
+        again = sg.propagate(state, 0.1, 10)
+        assert torch.equal(out, again)
+        return out, sg.stats, sg.nnz_local
+
+    parts = run_ranks(world, rank_body)
+    got = torch.cat([p[0] for p in parts])
+    assert sum(p[2] for p in parts) == entries
+    stats = [p[1] for p in parts]
+    if cover == "cover":
+        assert sum(s["pull_rows"] + s["push_rows"] for s in stats) < 0.75 * sum(s["pull_only_rows"] for s in stats)   # the cover pays
+    idx = torch.cat([torch.stack([u, w], 1), torch.stack([w, u], 1)])
+    whole = gnntf.normalize(gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=device), (n, n)), device=device), "symmetric")
+    del idx
+    want = gnntf.appnp_propagate(whole, H0, 0.1, 10)
+    # pushed partial sums regroup a row's additions; hub rows of ~10^5 entries cancel to ~1e-3 of their terms
+    scale = want.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)
+    err = ((got - want).abs() / scale).max().item()
+    assert err < 2e-4, err
+    assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.9999
+
+
+@pytest.mark.parametrize("world,n,entries,C", [(4, 2_000_000, 24_000_000, 32), (8, 4_000_000, 50_000_000, 64)])
+def test_edge_dropout_on_vertex_blocks_matches_one_gpu(gnntf, world, n, entries, C):
+    """Training-mode propagation (per-iteration edge dropout + re-normalisation) over ALL P blocks of one R-MAT graph on this GPU
+    against the one-GPU ppr_loop with the same seed: same masks whatever the partition, forward and dH0."""
+    from gnntf import sharded, sparse
+    from thread_comm import run_ranks
+    device = torch.device("cuda:0")
+    K, a, p, seed, first = 4, 0.1, 0.5, 77, 11
+    u, w = sharded.rmat_relabelled_pairs(n, entries // 2, seed=1, device=device)
+    gen = torch.Generator(device=device).manual_seed(2)
+    H0 = torch.rand(n, C, device=device, generator=gen) * 2 - 1
+    G = torch.rand(n, C, device=device, generator=gen) * 2 - 1
+    bounds = sharded.uniform_bounds(n, world)
+
+    def rank_body(comm):
+        lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+        mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
+        idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
+        sg = sharded.ShardedGraph(idx, torch.ones(idx.shape[0], device=device), bounds, comm=comm, edge_dropout=True)
+        scales = sg.dropped_scales(p, seed, first, K)
+        out = sg.propagate_dropped(H0[lo:hi], a, K, p, seed, first, scales)
+        grad = sg.propagate_dropped_backward(G[lo:hi], a, K, p, seed, first, scales)
+        return out, grad
+
+    parts = run_ranks(world, rank_body)
+    got, got_grad = torch.cat([q[0] for q in parts]), torch.cat([q[1] for q in parts])
+    idx = torch.cat([torch.stack([u, w], 1), torch.stack([w, u], 1)])
+    whole = gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=device), (n, n)), device=device)
+    del idx
+    D = sparse.dropped_degree_scales(whole, p, seed, first, K)
+    Hf = H0.clone().requires_grad_(True)
+    want = sparse.ppr_loop(lambda k, bwd=False: sparse.dropped_adjacency(whole, p, seed, first + k, D=D[k]), Hf, a, K)
+    want.backward(G)
+    for x, y in ((got, want.detach()), (got_grad, Hf.grad)):
+        scale = y.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)
+        assert ((x - y).abs() / scale).max().item() < 1e-4

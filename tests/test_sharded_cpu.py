@@ -79,6 +79,34 @@ def test_training_with_edge_dropout_on_vertex_blocks(world):
     launch(world, "train_dropout")
 
 
+@pytest.mark.parametrize("world,cover", [(5, "cover"), (7, "pull")])
+def test_blocks_as_threads_of_one_process(world, cover):
+    """The ranks as threads exchanging through shared memory (tests/thread_comm.py, the harness of the GPU full-size block test):
+    odd world sizes, checker backend, against the single-process oracle."""
+    import numpy as np
+    import torch
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd"), os.path.join(ROOT, "tests")]
+    import graphs
+    from dist_worker import OracleBackend
+    from gnntf import sharded
+    from oracle import gnntf_oracle as orc
+    from thread_comm import run_ranks
+    n = 1201
+    coo, vals, _ = graphs.rmat_symmetric_coo(n, 11000, seed=3)
+    H0 = np.random.default_rng(1).uniform(-1, 1, (n, 12)).astype(np.float32)
+    bounds = sharded.uniform_bounds(n, world)
+
+    def body(comm):
+        lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
+        mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
+        sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]), torch.from_numpy(vals[mine]), bounds, backend=OracleBackend(), comm=comm,
+                                  cover=cover, chunks=3)
+        return sg.propagate(sg.make_state(torch.from_numpy(H0[lo:hi].copy())), 0.1, 10).clone().numpy()
+    got = np.concatenate(run_ranks(world, body))
+    want = orc.appnp_propagate(coo, vals, (n, n), H0, a=0.1, iterations=10)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
 def test_choose_grid_and_columns():
     """Planning helpers: the grid cost model takes a MEASURED link rate (no built-in default), and the column
     chunks are whole 128-byte lines wherever the width allows."""
