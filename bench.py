@@ -466,6 +466,26 @@ def main():
                         GBs_per_link_and_direction=halo_bytes / max(t_x, 1e-9) / 1e9 / max(pv - 1, 1),
                         pull_only_bytes_per_rank_per_iteration=halo["max_pull_only_rows"] * C_local * 4)
 
+    # in-run parity evidence: sqrt(degree) x s is a fixed point of the propagation on a symmetric graph -- K more iterations through
+    # the very path that was timed (for N > 1: the plan, the kernels AND the RCCL exchange) must reproduce it
+    note("self check: fixed point of the propagation")
+    if sharded_path:
+        check_err = sg.fixed_point_error(state, a, K)
+    else:
+        deg = torch.empty(g.n_rows, dtype=torch.float32, device=device)
+        nat.check(lib.gnx_graph_colsum(g.handle, 0.0, 0, 0, nat.ptr(deg), nat.current_stream()))
+        E0 = deg.sqrt()[:, None] * (1.0 + torch.arange(C, dtype=torch.float32, device=device) / C)[None, :]
+        del deg
+        nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(E0), a, K, C, nat.ptr(out), nat.ptr(work),
+                                          nat.current_stream()))
+        from gnntf.sharded import max_relative_deviation
+        check_err = max_relative_deviation(out, E0)
+        del E0
+    self_check = {"what": "H0 = sqrt(degree) x s_c is a fixed point of H <- (1-a) A_hat H + a H0 on a symmetric graph: largest deviation "
+                          "after K iterations through the timed path, relative to max(|H0|, 1), max over ranks",
+                  "max_rel_err": check_err, "ok": bool(check_err < 1e-4)}
+    note(f"self check: {check_err:.2e}")
+
     # N > 1, second field (never the headline): the SAME graph replicated on every rank, each rank propagating C / N of the feature
     # columns -- no exchange at all, graph memory and prep grow with N.  Tells how far the vertex blocks are from a link-free bound.
     alt = None
@@ -519,7 +539,7 @@ def main():
                        "stored_entries_per_rank": nnz_local, "features": C, "iterations": K, "alpha": a,
                        "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (kernel_blocks if sharded_path else g.last_kernel()),
-                       "alt_grid_feature_slices": alt},
+                       "alt_grid_feature_slices": alt, "self_check": self_check},
             "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:

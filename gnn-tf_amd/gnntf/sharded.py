@@ -319,6 +319,15 @@ def cover_push_mask(row, col, owner, rank, n_local, bnd):
     return push
 
 
+def max_relative_deviation(got, want, rows_per_pass=1 << 22):
+    """max |got - want| / max(|want|, 1), in row slabs so that the temporaries stay small next to 40 GB operands."""
+    worst = 0.0
+    for r0 in range(0, got.shape[0], rows_per_pass):
+        g, w = got[r0:r0 + rows_per_pass], want[r0:r0 + rows_per_pass]
+        worst = max(worst, float(((g - w).abs() / w.abs().clamp_min(1.0)).max()))
+    return worst
+
+
 class _Lanes:
     """Two in-order lanes -- compute (the caller's stream) and exchange (a stream of its own) -- joined by
     events.  On CPU ranks there are no streams and everything runs in program order."""
@@ -403,11 +412,12 @@ class ShardedGraph:
         if normalized == "symmetric":
             deg = be.colsum(g0)
             self.comm.all_reduce(deg)
+            self.sqrt_degree = deg[lo:hi].sqrt()        # this rank's part of the eigenvector D^1/2 1 (eigenvalue 1 when A is symmetric)
             D = be.degree_scale(deg, "symmetric")
             nvals = be.scale_values(g0, D[lo:hi], D)
             del deg, D
         elif normalized == "none":
-            nvals = raw
+            nvals, self.sqrt_degree = raw, None
         else:
             raise Exception("Invalid matrix normalization")
         del g0, raw
@@ -796,6 +806,27 @@ class ShardedGraph:
         t = torch.tensor([best], dtype=torch.float64, device=self.device)
         self.comm.all_reduce(t, dist.ReduceOp.MAX)
         return float(t.item())
+
+    def fixed_point_error(self, state, a=0.1, iterations=10):
+        """In-run check of the whole vertex-block path (plan, kernels, exchange): for a SYMMETRIC graph H0 = sqrt(column sums) x s
+        (a different factor s_c per column) is a fixed point of H <- (1-a) A_hat H + a H0, so after any number of iterations every
+        element must still equal H0.  Returns the largest relative deviation over all ranks (rows of isolated vertices must stay 0).
+        Overwrites state.H0.  Collective."""
+        if self.sqrt_degree is None:
+            raise Exception("fixed_point_error: needs a symmetrically normalised graph")
+        C = state.H0.shape[1]
+        s = 1.0 + torch.arange(C, dtype=torch.float32, device=self.device) / C
+        order = self.row_order if self.row_order is not None else None
+        E0 = self.sqrt_degree[:, None] * s[None, :]
+        if self.world == 1 and order is not None:              # relabelled single block: propagate() expects the caller's order in H0_user
+            state.H0_user.copy_(E0)
+            state.H0.copy_(E0.index_select(0, order))
+        else:
+            state.H0.copy_(E0)
+        out = self.propagate(state, a, iterations)
+        err = torch.tensor([max_relative_deviation(out, E0)], dtype=torch.float64, device=self.device)
+        self.comm.all_reduce(err, dist.ReduceOp.MAX)
+        return float(err.item())
 
     def _sync(self):
         if self.device.type == "cuda":

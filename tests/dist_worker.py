@@ -317,6 +317,8 @@ def main():
     assert torch.equal(out, again), "propagate is not repeatable"
     zero = sg.propagate(state, a, 0)
     assert torch.equal(zero, H0), "K = 0 must return H0 in the caller's order"
+    if mode not in ("slices", "directed"):                          # symmetric unit-weight graphs: bench.py's in-run self check
+        assert sg.fixed_point_error(sg.make_state(H0.clone()), a, K) < 1e-5      # (overwrites the H0 it is given)
     one = sg.propagate(sg.make_state(H0, chunks=1) if sg.world > 1 else state, a, K)
     np.testing.assert_allclose(one.cpu().numpy(), out.cpu().numpy(), rtol=1e-6, atol=1e-7)   # chunking does not change a column's sums
 
