@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long seeded fuzz of the kernels against float64 numpy / torch (not part of the test suite: minutes, not seconds).
-    python tools/fuzz_kernels.py [cases] [seed]"""
+    python tests/fuzz_kernels.py [cases] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd"), os.path.join(ROOT, "tests")]

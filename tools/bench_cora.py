@@ -1,14 +1,12 @@
 #!/usr/bin/env python3
 """Config 2 timing (Cora-shaped APPNP, K=10, C=7): latency-bound regime.  ms per training epoch
-(layer-by-layer and fused) and eval forward latency on the HIP path, next to the numpy oracle's
-eval forward on the host."""
+(layer-by-layer and fused, eager and replayed from hipGraphs) and eval forward latency on the HIP path."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import torch
 import gnntf, graphs
-from oracle import gnntf_oracle as orc
 
 gnntf.set_default_device("cuda:0")
 coo, vals, shape, X = graphs.cora_shaped(seed=0)
@@ -40,9 +38,4 @@ for fused in (False, True):                                 # the same epochs re
         torch.cuda.synchronize(); times.append(time.time() - t0)
     out["captured_train_ms_per_epoch_fused" if fused else "captured_train_ms_per_epoch_layers"] = (times[1] - times[0]) / 200 * 1e3   # capture cost cancels
     out["capture_setup_ms_fused" if fused else "capture_setup_ms_layers"] = (times[0] - 100 * (times[1] - times[0]) / 200) * 1e3
-dense = [l for l in model.layers() if isinstance(l, gnntf.Dense)]
-weights = [(l.W.detach().cpu().numpy(), l.b.detach().cpu().numpy()) for l in dense]
-t0 = time.time()
-for _ in range(3): orc.appnp_forward_eval(coo, vals, shape, X, weights)
-out["oracle_numpy_eval_forward_ms"] = (time.time() - t0) / 3 * 1e3
 print(json.dumps(out, indent=1))
