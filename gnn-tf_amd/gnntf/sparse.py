@@ -342,6 +342,29 @@ class _PPRStep(torch.autograd.Function):
         return gH, gH0, None, None
 
 
+PAD_WIDTHS = True      # tools flip this for A/B runs
+
+
+def friendly_width(C: int) -> int:
+    """The row width (floats) the K-iteration loops run at.  A gather moves whole 128-byte lines and the kernels load 16 bytes
+    per lane when rows are 16-byte aligned: rows of 7 ... 31 floats are padded to the next power of two (a row then never
+    straddles a line it does not fill: C = 9 ... 15 run 26 % faster as 16, 20 ... 24 as 32), wider ones to the next multiple of
+    4 (C = 41 or 47 -- odd class counts -- would otherwise fall back to 4-byte loads).  The pad columns are zero and stay zero."""
+    if not PAD_WIDTHS or C <= 6:           # up to 6 floats the pad / un-pad copies cost what the wider loads save
+        return C
+    if C <= 32:
+        return 1 << (C - 1).bit_length()
+    return (C + 3) // 4 * 4
+
+
+def _padded(H: torch.Tensor, Cp: int) -> torch.Tensor:
+    if H.shape[1] == Cp:
+        return H
+    out = torch.zeros((H.shape[0], Cp), dtype=torch.float32, device=H.device)
+    out[:, :H.shape[1]] = H
+    return out
+
+
 class _PPRLoop(torch.autograd.Function):
     """K PPRIteration steps as ONE autograd node.  The step is linear in H, so the backward needs no
     stored activations: g_k = (1-a) A_k^T g_{k+1}, dH0 = g_0 + a * sum_k g_{k+1}.  In training mode
@@ -353,16 +376,18 @@ class _PPRLoop(torch.autograd.Function):
     def forward(ctx, H0, make_adj, a, K):
         ctx.make_adj, ctx.a, ctx.K = make_adj, a, K
         H0 = _as_f32_rows(H0).contiguous()
+        ctx.C = C = H0.shape[1]
+        H0 = _padded(H0, friendly_width(C))
         H = H0
         for k in range(K):
             H = _launch(make_adj(k, False), H, H0, 1.0 - a, a, nat.ACT_NONE)
-        return H
+        return H if H.shape[1] == C else H[:, :C].contiguous()
 
     @staticmethod
     def backward(ctx, g):
         # dH0 = g_0 + a (g_1 + ... + g_K): the gradients of the iterations are KEPT (as many as a tenth of the card's memory
         # holds, at most 15) and added up by one pass (gnx_linear_combination) instead of a read-modify-write of dH0 per iteration
-        g = g.contiguous()
+        g = _padded(g.contiguous(), friendly_width(ctx.C))
         room = int(0.1 * torch.cuda.get_device_properties(g.device).total_memory) // max(g.numel() * 4, 1)
         limit = max(2, min(LINCOMB_TERMS - 1, room))
         pending, total = [], None
@@ -372,7 +397,8 @@ class _PPRLoop(torch.autograd.Function):
                 total, pending = linear_combination(([(total, 1.0)] if total is not None else []) + pending), []
             g = _launch(ctx.make_adj(k, True), g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
         pending.append((g, 1.0))
-        return linear_combination(([(total, 1.0)] if total is not None else []) + pending), None, None, None
+        gH0 = linear_combination(([(total, 1.0)] if total is not None else []) + pending)
+        return (gH0 if gH0.shape[1] == ctx.C else gH0[:, :ctx.C].contiguous()), None, None, None
 
 
 LINCOMB_TERMS = 16
@@ -452,13 +478,15 @@ def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations
     H0 = _as_f32_rows(H0).contiguous()
     if g.n_rows != g.n_cols or H0.shape[0] != g.n_rows:
         raise Exception("appnp_propagate: needs a square graph matching H0")
+    C = H0.shape[1]
+    H0 = _padded(H0, friendly_width(C))
     out = torch.empty_like(H0)
     work = torch.empty_like(H0) if iterations > 1 else None
     with nat.on_device(H0.device):
         nat.check(nat.lib().gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(H0), float(a),
                                                 int(iterations), H0.shape[1], nat.ptr(out), nat.ptr(work),
                                                 nat.current_stream()))
-    return out
+    return out if out.shape[1] == C else out[:, :C].contiguous()
 
 
 def gather_rows(X: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:

@@ -713,3 +713,34 @@ def test_linear_combination_one_pass(gnntf, n, k):
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)    # (double rounding of the float64 emulation aside, the same bits)
     with pytest.raises(Exception, match="1 to 16 terms"):
         linear_combination([(dev(arrays[0]), 1.0)] * 17)
+
+
+@pytest.mark.parametrize("C", [7, 9, 21, 41, 127])
+def test_fused_loops_pad_odd_widths(gnntf, C):
+    """The K-iteration loops run odd widths at a friendlier row width (power of two up to 32, multiple of 4 beyond; zero pad
+    columns): same numbers as the unpadded run to float32 rounding, eval loop and training loop (forward and dH0)."""
+    from gnntf import sparse
+    n = 3000
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 40000, seed=C)
+    adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape), "symmetric")
+    rng = np.random.default_rng(C)
+    H0 = dev(rng.standard_normal((n, C)).astype(np.float32))
+    G = dev(rng.standard_normal((n, C)).astype(np.float32))
+    assert sparse.friendly_width(C) > C and sparse.friendly_width(C) % 4 == 0 and sparse.friendly_width(6) == 6 and sparse.friendly_width(64) == 64
+    results = []
+    for pad in (True, False):
+        sparse.PAD_WIDTHS = pad
+        try:
+            with torch.no_grad():
+                ev = gnntf.appnp_propagate(adj, H0, 0.1, 10)
+            Hf = H0.clone().requires_grad_(True)
+            tr = sparse.ppr_loop(lambda k, bwd=False: adj, Hf, 0.1, 10)
+            tr.backward(G)
+            results.append((ev, tr.detach(), Hf.grad))
+        finally:
+            sparse.PAD_WIDTHS = True
+    for x, y in zip(*results):
+        assert x.shape == (n, C) and x.is_contiguous()
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    want = orc.appnp_propagate(coo, vals, shape, H0.cpu().numpy(), a=0.1, iterations=10)
+    np.testing.assert_allclose(results[0][0].cpu().numpy(), want, rtol=RTOL, atol=ATOL)

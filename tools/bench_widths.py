@@ -52,7 +52,13 @@ def main():
         from gnntf.sparse import _launch
         ms = timed(lambda: _launch(adj, H, H0, 0.9, 0.1, 0, out=buf))
         b = bench.alg_bytes_per_iteration(n, nnz, C)
-        out["widths"].append({"C": C, "kernel": g.last_kernel(), "ms": ms, "edges_per_s": nnz / ms * 1e3,
+        kernel = g.last_kernel()
+        with torch.no_grad():
+            loop_ms = timed(lambda: gnntf.appnp_propagate(adj, H0, 0.1, 10), reps=3, warm=1)
+            gnntf.sparse.PAD_WIDTHS = False
+            unpadded_ms = timed(lambda: gnntf.appnp_propagate(adj, H0, 0.1, 10), reps=3, warm=1)
+            gnntf.sparse.PAD_WIDTHS = True
+        out["widths"].append({"C": C, "kernel": kernel, "ms": ms, "k10_loop_ms": loop_ms, "k10_loop_unpadded_ms": unpadded_ms, "loop_kernel": g.last_kernel(), "edges_per_s": nnz / ms * 1e3,
                               "alg_GBs": b / ms / 1e6, "frac": b / ms / 1e6 / bench.HBM_PEAK_GBS})
         del H, H0, buf
     if not args.skip_train:
