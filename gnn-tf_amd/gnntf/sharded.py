@@ -915,15 +915,18 @@ class ShardedPPRLoop(Layer):
         return architecture.top_shape()
 
     def _propagate(self, which, H0):
+        C = H0.shape[1]
+        H0 = sparse._padded(H0.to(torch.float32), sparse.friendly_width(C))      # odd class counts run at a line-friendly row width
         state = self._states.get(which)
         if state is None or tuple(state.H0.shape) != tuple(H0.shape):
-            state = self._states[which] = self.graph.make_state(H0)
+            state = self._states[which] = self.graph.make_state(H0.clone())
         elif self.graph.row_order is not None:
             state.H0_user.copy_(H0)
             state.H0.copy_(H0.index_select(0, self.graph.row_order))
         else:
             state.H0.copy_(H0)
-        return self.graph.propagate(state, self.restart_probability, self.iterations).clone()
+        out = self.graph.propagate(state, self.restart_probability, self.iterations)
+        return out.clone() if out.shape[1] == C else out[:, :C].contiguous()
 
     def __forward__(self, architecture, features):
         H0 = self.H0.value
