@@ -218,10 +218,10 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
 // ---- narrow path: G lanes per row, 256/G rows per block ---------------------------------------
 // PIPE: the (col, val) pairs of batch b+1 are fetched while the gathers of batch b are in flight.
 template <int VEC, int G, int U, bool PIPE>
-__global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
+__device__ __forceinline__ void group_rows(const SpmmArgs &p, int64_t block) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
-    const int64_t slot = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+    const int64_t slot = block * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;   // degree-binned: the rows of one wave have similar lengths
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
@@ -290,6 +290,11 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
         }
         epilogue_store<VEC>(p, row, c, active, acc);
     }
+}
+
+template <int VEC, int G, int U, bool PIPE>
+__global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
+    group_rows<VEC, G, U, PIPE>(p, blockIdx.x);
 }
 
 // ---- GCNII layer: SpMM + mix + C x C transform on the matrix cores + activation, one launch ------------------------
@@ -416,11 +421,11 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial(const SpmmArgs p) {
 // Narrow features: a chunk's entries are dealt round-robin to the wave's 64/G sub-groups of G lanes
 // (each sub-group gathers whole C-wide rows), then the sub-group sums are added with a fixed xor tree.
 template <int VEC, int G, int U>
-__global__ __launch_bounds__(256) void k_spmm_long_partial_group(const SpmmArgs p) {
+__device__ __forceinline__ void long_chunks_group(const SpmmArgs &p, int64_t block) {
     constexpr int NS = 64 / G;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t cslot = (int64_t)blockIdx.x * 4 + wib;
+    const int64_t cslot = block * 4 + wib;
     if (cslot >= p.n_chunks) return;
     const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;   // column-window order
     const int32_t li = p.chunk_long[chunk];
@@ -461,6 +466,21 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_group(const SpmmArgs 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] += __shfl_xor(acc[v], off);
     if (sub == 0 && active) vstore<VEC>(p.partial + chunk * (int64_t)p.C + c, acc);
+}
+
+template <int VEC, int G, int U>
+__global__ __launch_bounds__(256) void k_spmm_long_partial_group(const SpmmArgs p) {
+    long_chunks_group<VEC, G, U>(p, blockIdx.x);
+}
+
+// Short rows and the chunks of the long rows in ONE launch, for graphs with few chunks (a citation-graph-sized matrix has a few
+// hundred): a chunk is one wave walking 512 entries, so a launch of a few hundred waves is bound by the latency of that walk
+// (0.11 ms at C = 128) while most of the card idles; here the chunk blocks are dealt first and the short rows fill the rest of
+// the card under them.  Same per-row arithmetic as the two separate launches; k_spmm_long_reduce follows as before.
+template <int VEC, int G, bool PIPE>
+__global__ __launch_bounds__(256) void k_spmm_group_and_chunks(const SpmmArgs p, int chunk_blocks) {
+    if ((int)blockIdx.x < chunk_blocks) long_chunks_group<VEC, G, 4>(p, blockIdx.x);
+    else group_rows<VEC, G, 4, PIPE>(p, (int64_t)blockIdx.x - chunk_blocks);
 }
 
 template <int VEC>
@@ -792,6 +812,26 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
 #undef GNX_GROUP
 }
 
+// few chunks (see k_spmm_group_and_chunks): one launch for the short rows and the chunks, then the reduce
+constexpr int64_t MERGE_MAX_CHUNKS = 16384;        // two card-fills of chunk waves; beyond that the chunk launch is bandwidth-bound by itself
+
+template <int VEC>
+const char *launch_rows_and_chunks(const SpmmArgs &p, hipStream_t s) {
+    const int lanes = (p.C + VEC - 1) / VEC;
+    if (lanes > 32 || p.n_long == 0 || p.n_chunks > MERGE_MAX_CHUNKS || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;
+    const unsigned cb = blocks_for(p.n_chunks, 4);
+    const char *name;
+#define GNX_BOTH(G, RPB_, PIPE_)                                                                                          \
+    hipLaunchKernelGGL((k_spmm_group_and_chunks<VEC, G, PIPE_>), dim3(cb + blocks_for(p.n_rows, RPB_)), dim3(256), 0, s, p, (int)cb)
+    if (lanes > 16)     { GNX_BOTH(32, 8, false); name = "spmm_group32+chunks"; }
+    else if (lanes > 8) { GNX_BOTH(16, 16, false); name = "spmm_group16+chunks"; }
+    else if (lanes > 4) { GNX_BOTH(8, 32, true); name = "spmm_group8+chunks"; }
+    else                { GNX_BOTH(4, 64, true); name = "spmm_group4+chunks"; }
+#undef GNX_BOTH
+    GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
+    return name;
+}
+
 template <int VEC>
 void launch_long(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
@@ -880,9 +920,9 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
         GNX_HIP(hipGetLastError());
         return GNX_OK;
     }
-    if (vec == 4)      { name = launch_rows<4>(p, s); if (m.n_long) launch_long<4>(p, s); }
-    else if (vec == 2) { name = launch_rows<2>(p, s); if (m.n_long) launch_long<2>(p, s); }
-    else               { name = launch_rows<1>(p, s); if (m.n_long) launch_long<1>(p, s); }
+    if (vec == 4)      { if (!(name = launch_rows_and_chunks<4>(p, s))) { name = launch_rows<4>(p, s); if (m.n_long) launch_long<4>(p, s); } }
+    else if (vec == 2) { if (!(name = launch_rows_and_chunks<2>(p, s))) { name = launch_rows<2>(p, s); if (m.n_long) launch_long<2>(p, s); } }
+    else               { if (!(name = launch_rows_and_chunks<1>(p, s))) { name = launch_rows<1>(p, s); if (m.n_long) launch_long<1>(p, s); } }
     g->last_kernel = name;
     GNX_HIP(hipGetLastError());
     return GNX_OK;

@@ -62,7 +62,12 @@ for case in range(cases):
             H = dev(H0)
             for _ in range(K):
                 H = gnntf.ppr_step(adj, H, dev(H0), 0.15)
-            assert torch.equal(gnntf.appnp_propagate(adj, dev(H0), 0.15, K), H), f"kloop case {case}"
+            got = gnntf.appnp_propagate(adj, dev(H0), 0.15, K)
+            if gnntf.sparse.friendly_width(C) == C:
+                assert torch.equal(got, H), f"kloop case {case}"
+            else:        # odd widths run the loop at a padded row width: other kernel variants, other summation grouping on hub rows
+                longest = float(np.sqrt(max(np.bincount(idx[:, 0]).max(), 1)))
+                assert torch.allclose(got, H, rtol=1e-5, atol=2e-6 * longest), f"kloop case {case}: {float((got - H).abs().max())}"
             stats["kloop"] += 1
         elif kind == 3 and nnz:
             adj = gnntf.normalize(g, "symmetric")

@@ -46,7 +46,7 @@ def test_config3_arxiv_full_size_gcn_vs_oracle(gnntf):
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
     decided = np.sort(want, axis=1)[:, -1] - np.sort(want, axis=1)[:, -2] > 1e-5        # rows whose top-2 logits are not a float tie
     assert (got.argmax(1)[decided] == want.argmax(1)[decided]).all() and decided.mean() > 0.5
-    assert model.graph.last_kernel() in ("spmm_group16", "spmm_group32")
+    assert model.graph.last_kernel() in ("spmm_group16+chunks", "spmm_group32+chunks")     # few hub chunks: one launch with the short rows
 
 
 def eigenvector_check(gnntf, g, adj, C, K=10):
