@@ -110,39 +110,39 @@ __global__ void k_check_csr(const int64_t *__restrict__ rowptr, const int32_t *_
     }
 }
 
-__global__ void k_flag_long(const int64_t *__restrict__ rowptr, int64_t n_rows, int32_t *__restrict__ flag,
-                            int64_t *__restrict__ cnt) {
+__global__ void k_flag_long(const int64_t *__restrict__ rowptr, int64_t n_rows, int long_row, int long_chunk,
+                            int32_t *__restrict__ flag, int64_t *__restrict__ cnt) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     int64_t d = rowptr[r + 1] - rowptr[r];
-    bool lg = d > LONG_ROW;
+    bool lg = d > long_row;
     flag[r] = lg ? 1 : 0;
-    cnt[r] = lg ? (d + LONG_CHUNK - 1) / LONG_CHUNK : 0;
+    cnt[r] = lg ? (d + long_chunk - 1) / long_chunk : 0;
 }
 
-// sort key of the degree-binned row order: ORDER_CLAMP - min(entries, ORDER_CLAMP), so an ascending stable sort puts the
+// sort key of the degree-binned row order: clamp - min(entries, clamp), so an ascending stable sort puts the
 // heaviest rows first and keeps ascending row ids inside a bin.  The clamp covers every row the sub-wave kernels take
-// (up to LONG_ROW entries): the rows that share a wave then have EQUAL lengths, also in the 256..512 range
-constexpr int ORDER_CLAMP = LONG_ROW < 65535 ? LONG_ROW : 65535;
-__global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows, uint16_t *__restrict__ keys,
+// (up to the threshold entries): the rows that share a wave then have EQUAL lengths, also in the 256..512 range
+__global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows, int clamp, uint16_t *__restrict__ keys,
                              int32_t *__restrict__ ids) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     int64_t d = rowptr[r + 1] - rowptr[r];
-    keys[r] = (uint16_t)(ORDER_CLAMP - (d < ORDER_CLAMP ? d : ORDER_CLAMP));
+    keys[r] = (uint16_t)(clamp - (d < clamp ? d : clamp));
     ids[r] = (int32_t)r;
 }
 
-__global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, const int32_t *__restrict__ pos,
+__global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, int long_row, int long_chunk,
+                            const int32_t *__restrict__ pos,
                             const int64_t *__restrict__ cpos, int32_t *__restrict__ long_rows,
                             int64_t *__restrict__ long_chunk_ptr, int32_t *__restrict__ chunk_long) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     int64_t d = rowptr[r + 1] - rowptr[r];
-    if (d <= LONG_ROW) return;
+    if (d <= long_row) return;
     const int32_t p = pos[r];
     const int64_t c0 = cpos[r];
-    const int64_t nc = (d + LONG_CHUNK - 1) / LONG_CHUNK;
+    const int64_t nc = (d + long_chunk - 1) / long_chunk;
     long_rows[p] = (int32_t)r;
     long_chunk_ptr[p] = c0;
     for (int64_t c = 0; c < nc; ++c) chunk_long[c0 + c] = p;
@@ -152,12 +152,12 @@ __global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, 
 // that at any time the long-row waves gather from one window of columns and its hub rows stay cached
 __global__ void k_chunk_keys(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
                              const int32_t *__restrict__ long_rows, const int64_t *__restrict__ long_chunk_ptr,
-                             const int32_t *__restrict__ chunk_long, int64_t n_chunks, uint32_t *__restrict__ keys,
-                             int32_t *__restrict__ ids) {
+                             const int32_t *__restrict__ chunk_long, int64_t n_chunks, int long_chunk,
+                             uint32_t *__restrict__ keys, int32_t *__restrict__ ids) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const int32_t li = chunk_long[c];
-    const int64_t beg = rowptr[long_rows[li]] + (c - long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t beg = rowptr[long_rows[li]] + (c - long_chunk_ptr[li]) * long_chunk;
     keys[c] = (uint32_t)colidx[beg];
     ids[c] = (int32_t)c;
 }
@@ -212,14 +212,17 @@ void free_csr(Csr &m) {
 
 int build_long_plan(Csr &m, hipStream_t s) {
     m.n_long = 0; m.n_chunks = 0;
+    m.long_row = m.n_rows < SMALL_ROWS ? SMALL_LONG_ROW : LONG_ROW;          // see gnx_internal.h
+    m.long_chunk = m.n_rows < SMALL_ROWS ? SMALL_LONG_ROW : LONG_CHUNK;
+    const int order_clamp = m.long_row < 65535 ? m.long_row : 65535;
     if (m.n_rows == 0) return GNX_OK;
     {   // degree-binned row order
         DevBuf k0, k1, ids, t;
         GNX_HIP(k0.alloc(m.n_rows * 2)); GNX_HIP(k1.alloc(m.n_rows * 2)); GNX_HIP(ids.alloc(m.n_rows * sizeof(int32_t)));
         GNX_HIP(hipMalloc((void **)&m.row_order, m.n_rows * sizeof(int32_t)));
-        hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, k0.as<uint16_t>(),
+        hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, order_clamp, k0.as<uint16_t>(),
                            ids.as<int32_t>());
-        const unsigned key_bits = bits_for((uint64_t)ORDER_CLAMP + 1);
+        const unsigned key_bits = bits_for((uint64_t)order_clamp + 1);
         size_t tb = 0;
         GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint16_t>(), k1.as<uint16_t>(), ids.as<int32_t>(), m.row_order,
                                           (size_t)m.n_rows, 0u, key_bits, s));
@@ -234,8 +237,8 @@ int build_long_plan(Csr &m, hipStream_t s) {
     GNX_HIP(cnt.alloc(m.n_rows * sizeof(int64_t)));
     GNX_HIP(pos.alloc(m.n_rows * sizeof(int32_t)));
     GNX_HIP(cpos.alloc(m.n_rows * sizeof(int64_t)));
-    hipLaunchKernelGGL(k_flag_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, flag.as<int32_t>(),
-                       cnt.as<int64_t>());
+    hipLaunchKernelGGL(k_flag_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, m.long_row, m.long_chunk,
+                       flag.as<int32_t>(), cnt.as<int64_t>());
     size_t t1 = 0, t2 = 0;
     GNX_HIP(rocprim::exclusive_scan(nullptr, t1, flag.as<int32_t>(), pos.as<int32_t>(), (int32_t)0, (size_t)m.n_rows,
                                     rocprim::plus<int32_t>(), s));
@@ -259,15 +262,15 @@ int build_long_plan(Csr &m, hipStream_t s) {
     GNX_HIP(hipMalloc((void **)&m.long_rows, m.n_long * sizeof(int32_t)));
     GNX_HIP(hipMalloc((void **)&m.long_chunk_ptr, (m.n_long + 1) * sizeof(int64_t)));
     GNX_HIP(hipMalloc((void **)&m.chunk_long, m.n_chunks * sizeof(int32_t)));
-    hipLaunchKernelGGL(k_fill_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, pos.as<int32_t>(),
-                       cpos.as<int64_t>(), m.long_rows, m.long_chunk_ptr, m.chunk_long);
+    hipLaunchKernelGGL(k_fill_long, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, m.long_row, m.long_chunk,
+                       pos.as<int32_t>(), cpos.as<int64_t>(), m.long_rows, m.long_chunk_ptr, m.chunk_long);
     GNX_HIP(hipMemcpyAsync(m.long_chunk_ptr + m.n_long, &m.n_chunks, 8, hipMemcpyHostToDevice, s));
     {   // column-window order of the chunks
         DevBuf k0, k1, ids, t;
         GNX_HIP(k0.alloc(m.n_chunks * 4)); GNX_HIP(k1.alloc(m.n_chunks * 4)); GNX_HIP(ids.alloc(m.n_chunks * 4));
         GNX_HIP(hipMalloc((void **)&m.chunk_order, m.n_chunks * sizeof(int32_t)));
         hipLaunchKernelGGL(k_chunk_keys, dim3(blocks_for(m.n_chunks)), dim3(256), 0, s, m.rowptr, m.colidx, m.long_rows,
-                           m.long_chunk_ptr, m.chunk_long, m.n_chunks, k0.as<uint32_t>(), ids.as<int32_t>());
+                           m.long_chunk_ptr, m.chunk_long, m.n_chunks, m.long_chunk, k0.as<uint32_t>(), ids.as<int32_t>());
         size_t tb = 0;
         GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint32_t>(), k1.as<uint32_t>(), ids.as<int32_t>(), m.chunk_order,
                                           (size_t)m.n_chunks, 0u, 32u, s));

@@ -42,6 +42,11 @@ void set_error(const char *fmt, ...);
 #endif
 constexpr int LONG_ROW = GNX_LONG_ROW;
 constexpr int LONG_CHUNK = GNX_LONG_CHUNK;
+// Small structures (a citation graph: 10^5 rows) are bound by the LATENCY of their longest walk, not by bandwidth: one
+// 512-entry row is 128 dependent gather rounds of a 16-lane group (0.13 ms -- the whole launch).  Below 2^20 rows the plan
+// therefore cuts rows at 128 entries into 128-entry chunks, and the sub-wave kernels take chunks and short rows in one launch.
+constexpr int SMALL_ROWS = 1 << 20;
+constexpr int SMALL_LONG_ROW = GNX_LONG_ROW < 128 ? GNX_LONG_ROW : 128;
 
 // One CSR-like structure (the matrix itself, or its transpose).
 struct Csr {
@@ -50,6 +55,7 @@ struct Csr {
     int32_t *colidx = nullptr;  // [nnz]
     // long-row split plan
     int64_t n_long = 0, n_chunks = 0;
+    int long_row = LONG_ROW, long_chunk = LONG_CHUNK;   // this structure's threshold / chunk length (set by build_long_plan)
     int32_t *long_rows = nullptr;       // [n_long] row ids
     int64_t *long_chunk_ptr = nullptr;  // [n_long+1] first chunk of each long row
     int32_t *chunk_long = nullptr;      // [n_chunks] index into long_rows
@@ -167,6 +173,7 @@ struct SpmmArgs {
     const int32_t *row_order;
     float *partial;
     int64_t n_long, n_chunks;
+    int long_row, long_chunk;
     int tune;
     bool skip_empty;           // GNX_ACT_SKIP_EMPTY: rows without entries are left untouched
     DropFuse fuse;

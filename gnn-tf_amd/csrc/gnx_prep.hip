@@ -56,7 +56,7 @@ __device__ __forceinline__ float t_value(const float *__restrict__ raw, const fl
 template <bool DROPOUT>
 __global__ void k_colsum_short(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
                                const int32_t *__restrict__ t_perm, const float *__restrict__ raw,
-                               const float *__restrict__ t_raw, Drop d, int64_t n_cols, float *__restrict__ out) {
+                               const float *__restrict__ t_raw, Drop d, int64_t n_cols, int long_row, float *__restrict__ out) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t j = gid >> 3;
     const int sub = (int)(gid & 7);
@@ -64,7 +64,7 @@ __global__ void k_colsum_short(const int64_t *__restrict__ t_rowptr, const int32
     bool is_long = false;
     if (j < n_cols) {
         const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
-        is_long = (e - b) > LONG_ROW;
+        is_long = (e - b) > long_row;
         if (!is_long)
             for (int64_t p = b + sub; p < e; p += 8) acc += t_value<DROPOUT>(raw, t_raw, t_perm, d, p, t_colidx[p], (int32_t)j);
     }
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_colsum_long(const int64_t *__restrict__
 // so every stream's sums are bit for bit what the single-stream kernels give.  out[s * n_cols + j].
 template <int NS>
 __global__ void k_colsum_short_multi(const int64_t *__restrict__ t_rowptr, const int32_t *__restrict__ t_colidx,
-                                     const float *__restrict__ t_raw, Drop d, int64_t n_cols, float *__restrict__ out) {
+                                     const float *__restrict__ t_raw, Drop d, int64_t n_cols, int long_row, float *__restrict__ out) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t j = gid >> 3;
     const int sub = (int)(gid & 7);
@@ -110,7 +110,7 @@ __global__ void k_colsum_short_multi(const int64_t *__restrict__ t_rowptr, const
     bool is_long = false;
     if (j < n_cols) {
         const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
-        is_long = (e - b) > LONG_ROW;
+        is_long = (e - b) > long_row;
         if (!is_long) {
             const uint64_t kc = key_col(d, j);
             for (int64_t p = b + sub; p < e; p += 8) {
@@ -262,8 +262,8 @@ int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t str
     if (t.n_rows == 0) return GNX_OK;
     const bool drop = dropout_p > 0.f;
     const unsigned nb = blocks_for(t.n_rows * 8);
-    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, d_colsum_out);
-    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, d_colsum_out);
+    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, t.long_row, d_colsum_out);
+    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, t.long_row, d_colsum_out);
     if (t.n_long > 0) {
         if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
         else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
@@ -298,7 +298,7 @@ int gnx_graph_colsum_streams(gnx_graph_t g, float dropout_p, uint64_t seed, uint
         const int left = n_streams - k0;
 #define GNX_MULTI(NS)                                                                                                                  \
         do {                                                                                                                           \
-            hipLaunchKernelGGL(k_colsum_short_multi<NS>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, t.n_rows, out);    \
+            hipLaunchKernelGGL(k_colsum_short_multi<NS>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, t.n_rows, t.long_row, out); \
             if (t.n_long > 0)                                                                                                          \
                 hipLaunchKernelGGL(k_colsum_long_multi<NS>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, \
                                    t.long_rows, t.n_rows, out);                                                                        \

@@ -15,7 +15,7 @@
 //   * narrow features: G = 4..32 lanes per row, 64/G rows per wave, rows taken in a degree-binned
 //     order (Csr::row_order) so that the rows sharing a wave have similar lengths; for G <= 8 the next
 //     (col, val) batch is prefetched behind the gathers;
-//   * power-law rows: a row with more than LONG_ROW entries is cut into LONG_CHUNK-entry chunks summed
+//   * power-law rows: a row with more than p.long_row entries is cut into p.long_chunk-entry chunks summed
 //     by separate waves into a partial slab (wide: lanes across columns; narrow: sub-groups of lanes
 //     across the chunk's entries + a fixed xor tree), then added in chunk order by a second kernel
 //     (fixed order: results are bitwise reproducible, no float atomics).  Chunks are processed in
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
     if (slot >= p.n_rows) return;
     const int64_t row = (p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
-    if (end - beg > LONG_ROW) return;  // k_spmm_long_* take it
+    if (end - beg > p.long_row) return;  // k_spmm_long_* take it
     if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY: the row already holds alpha * H0 from an earlier iteration
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
         const int c = c0 + lane * VEC;
@@ -225,7 +225,7 @@ __device__ __forceinline__ void group_rows(const SpmmArgs &p, int64_t block) {
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;   // degree-binned: the rows of one wave have similar lengths
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
-    if (end - beg > LONG_ROW) return;
+    if (end - beg > p.long_row) return;
     if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
         const int c = c0 + sub * VEC;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
 // A 512-thread block: every wave gathers a tile of 16 rows (4 NT lanes of float4 per row, U entries in flight per lane,
 // rows in degree-binned order), leaves the mixed rows in its LDS tile -- they never go to HBM -- multiplies the tile by
 // M (shared by the block in LDS, row stride = 4 mod 32 banks) with v_mfma_f32_16x16x4_f32 (exact f32), and stores whole
-// rows.  C = 16 NT for NT in {1, 2, 4}; rows longer than LONG_ROW are left to the long-row kernels + the dense kernel.
+// rows.  C = 16 NT for NT in {1, 2, 4}; rows longer than p.long_row are left to the long-row kernels + the dense kernel.
 template <int NT, int U, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const float *__restrict__ M, int64_t ldm) {
     constexpr int C = 16 * NT, G = 4 * NT, RPP = 64 / G, PASSES = 16 / RPP, STRIDE = C + 4;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const
             row = p.row_order ? (int64_t)p.row_order[slot] : slot;
             beg = p.rowptr[row]; end = p.rowptr[row + 1];
         }
-        live[ps] = row >= 0 && end - beg <= LONG_ROW;
+        live[ps] = row >= 0 && end - beg <= p.long_row;
         rows[ps] = row;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         if (live[ps]) {
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial(const SpmmArgs p) {
     const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;   // column-window order
     const int32_t li = p.chunk_long[chunk];
     const int64_t row = p.long_rows[li];
-    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * p.long_chunk;
     const int64_t rend = p.rowptr[row + 1];
-    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    const int64_t end = beg + p.long_chunk < rend ? beg + p.long_chunk : rend;
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
         const int c = c0 + lane * VEC;
         const bool active = c < p.C;
@@ -430,9 +430,9 @@ __device__ __forceinline__ void long_chunks_group(const SpmmArgs &p, int64_t blo
     const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;   // column-window order
     const int32_t li = p.chunk_long[chunk];
     const int64_t row = p.long_rows[li];
-    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * p.long_chunk;
     const int64_t rend = p.rowptr[row + 1];
-    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    const int64_t end = beg + p.long_chunk < rend ? beg + p.long_chunk : rend;
     const int sub = lane / G;
     const int c = (lane % G) * VEC;
     const bool active = c < p.C;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_wave_drop(const SpmmArgs p) {
     const int64_t row = (int64_t)blockIdx.x * WPB + wib;
     if (row >= p.n_rows) return;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
-    if (end - beg > LONG_ROW) return;
+    if (end - beg > p.long_row) return;
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
         const int c = c0 + lane * VEC;
         const bool active = c < p.C;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
-    if (end - beg > LONG_ROW) return;
+    if (end - beg > p.long_row) return;
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
         const int c = c0 + sub * VEC;
         const bool active = c < p.C;
@@ -595,9 +595,9 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_drop(const SpmmArgs p
     const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;
     const int32_t li = p.chunk_long[chunk];
     const int64_t row = p.long_rows[li];
-    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * p.long_chunk;
     const int64_t rend = p.rowptr[row + 1];
-    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    const int64_t end = beg + p.long_chunk < rend ? beg + p.long_chunk : rend;
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
         const int c = c0 + lane * VEC;
         const bool active = c < p.C;
@@ -621,9 +621,9 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_group_drop(const Spmm
     const int64_t chunk = p.chunk_order ? (int64_t)p.chunk_order[cslot] : cslot;
     const int32_t li = p.chunk_long[chunk];
     const int64_t row = p.long_rows[li];
-    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * LONG_CHUNK;
+    const int64_t beg = p.rowptr[row] + (chunk - p.long_chunk_ptr[li]) * p.long_chunk;
     const int64_t rend = p.rowptr[row + 1];
-    const int64_t end = beg + LONG_CHUNK < rend ? beg + LONG_CHUNK : rend;
+    const int64_t end = beg + p.long_chunk < rend ? beg + p.long_chunk : rend;
     const int sub = lane / G;
     const int c = (lane % G) * VEC;
     const bool active = c < p.C;
@@ -813,12 +813,11 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
 }
 
 // few chunks (see k_spmm_group_and_chunks): one launch for the short rows and the chunks, then the reduce
-constexpr int64_t MERGE_MAX_CHUNKS = 16384;        // two card-fills of chunk waves; beyond that the chunk launch is bandwidth-bound by itself
 
 template <int VEC>
 const char *launch_rows_and_chunks(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
-    if (lanes > 32 || p.n_long == 0 || p.n_chunks > MERGE_MAX_CHUNKS || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;
+    if (lanes > 32 || p.n_long == 0 || p.n_rows >= SMALL_ROWS || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;
     const unsigned cb = blocks_for(p.n_chunks, 4);
     const char *name;
 #define GNX_BOTH(G, RPB_, PIPE_)                                                                                          \
@@ -900,7 +899,7 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
 #else
     p.tune = 0;
 #endif
-    p.n_long = m.n_long; p.n_chunks = m.n_chunks;
+    p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     p.partial = nullptr;
     p.skip_empty = (p.act & GNX_ACT_SKIP_EMPTY) != 0 && p.diag == nullptr;
     p.act &= ~GNX_ACT_SKIP_EMPTY;
@@ -1080,7 +1079,7 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
     p.X = d_H; p.ldx = C; p.H0 = d_H0; p.ldh0 = C; p.beta = beta; p.alpha = a; p.act = act; p.out = d_out; p.ldo = C; p.C = (int)C;
     p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.row_order = m.row_order;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
-    p.n_long = m.n_long; p.n_chunks = m.n_chunks;
+    p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     const unsigned grid = blocks_for(blocks_for(m.n_rows, 16), 8);
     if (C == 64)      hipLaunchKernelGGL((k_spmm_gcnii<4, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
     else if (C == 32) hipLaunchKernelGGL((k_spmm_gcnii<2, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);

@@ -916,7 +916,7 @@ class ShardedPPRLoop(Layer):
 
     def _propagate(self, which, H0):
         C = H0.shape[1]
-        H0 = sparse._padded(H0.to(torch.float32), sparse.friendly_width(C))      # odd class counts run at a line-friendly row width
+        H0 = sparse._padded(H0.to(torch.float32), sparse.friendly_width(C, self.graph.n_global))      # odd class counts run at a line-friendly row width
         state = self._states.get(which)
         if state is None or tuple(state.H0.shape) != tuple(H0.shape):
             state = self._states[which] = self.graph.make_state(H0.clone())

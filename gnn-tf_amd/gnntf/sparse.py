@@ -345,12 +345,15 @@ class _PPRStep(torch.autograd.Function):
 PAD_WIDTHS = True      # tools flip this for A/B runs
 
 
-def friendly_width(C: int) -> int:
+PAD_MIN_ROWS = 1 << 16      # smaller graphs are launch-bound: the pad / slice launches would cost more than the loads save
+
+
+def friendly_width(C: int, n_rows: int = PAD_MIN_ROWS) -> int:
     """The row width (floats) the K-iteration loops run at.  A gather moves whole 128-byte lines and the kernels load 16 bytes
     per lane when rows are 16-byte aligned: rows of 7 ... 31 floats are padded to the next power of two (a row then never
     straddles a line it does not fill: C = 9 ... 15 run 26 % faster as 16, 20 ... 24 as 32), wider ones to the next multiple of
     4 (C = 41 or 47 -- odd class counts -- would otherwise fall back to 4-byte loads).  The pad columns are zero and stay zero."""
-    if not PAD_WIDTHS or C <= 6:           # up to 6 floats the pad / un-pad copies cost what the wider loads save
+    if not PAD_WIDTHS or C <= 6 or n_rows < PAD_MIN_ROWS:     # up to 6 floats the pad / un-pad copies cost what the wider loads save
         return C
     if C <= 32:
         return 1 << (C - 1).bit_length()
@@ -377,7 +380,7 @@ class _PPRLoop(torch.autograd.Function):
         ctx.make_adj, ctx.a, ctx.K = make_adj, a, K
         H0 = _as_f32_rows(H0).contiguous()
         ctx.C = C = H0.shape[1]
-        H0 = _padded(H0, friendly_width(C))
+        H0 = _padded(H0, friendly_width(C, H0.shape[0]))
         H = H0
         for k in range(K):
             H = _launch(make_adj(k, False), H, H0, 1.0 - a, a, nat.ACT_NONE)
@@ -387,7 +390,7 @@ class _PPRLoop(torch.autograd.Function):
     def backward(ctx, g):
         # dH0 = g_0 + a (g_1 + ... + g_K): the gradients of the iterations are KEPT (as many as a tenth of the card's memory
         # holds, at most 15) and added up by one pass (gnx_linear_combination) instead of a read-modify-write of dH0 per iteration
-        g = _padded(g.contiguous(), friendly_width(ctx.C))
+        g = _padded(g.contiguous(), friendly_width(ctx.C, g.shape[0]))
         room = int(0.1 * torch.cuda.get_device_properties(g.device).total_memory) // max(g.numel() * 4, 1)
         limit = max(2, min(LINCOMB_TERMS - 1, room))
         pending, total = [], None
@@ -479,7 +482,7 @@ def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations
     if g.n_rows != g.n_cols or H0.shape[0] != g.n_rows:
         raise Exception("appnp_propagate: needs a square graph matching H0")
     C = H0.shape[1]
-    H0 = _padded(H0, friendly_width(C))
+    H0 = _padded(H0, friendly_width(C, H0.shape[0]))
     out = torch.empty_like(H0)
     work = torch.empty_like(H0) if iterations > 1 else None
     with nat.on_device(H0.device):

@@ -125,7 +125,7 @@ def train_on_blocks(rank, world, dev, backend, graph_dropout=0.0):
     import gnntf
     gnntf.set_default_device(dev)
     gnntf.set_seed(33)
-    n, F, hidden, classes, K, a, epochs = 600, 10, 8, 7, 6, 0.1, 8      # 7 classes: the loop runs at a padded width of 8
+    n, F, hidden, classes, K, a, epochs = 600, 10, 8, 7, 6, 0.1, 8      # (an odd class count)
     coo, vals, shape = graphs.rmat_symmetric_coo(n, 5000, seed=8)
     rng = np.random.default_rng(8)
     X = rng.standard_normal((n, F)).astype(np.float32)

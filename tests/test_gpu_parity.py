@@ -722,13 +722,14 @@ def test_fused_loops_pad_odd_widths(gnntf, C):
     """The K-iteration loops run odd widths at a friendlier row width (power of two up to 32, multiple of 4 beyond; zero pad
     columns): same numbers as the unpadded run to float32 rounding, eval loop and training loop (forward and dH0)."""
     from gnntf import sparse
-    n = 3000
-    coo, vals, shape = graphs.rmat_symmetric_coo(n, 40000, seed=C)
+    n = 70000                                      # (graphs below 2^16 rows are launch-bound and stay unpadded)
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 400000, seed=C)
     adj = gnntf.normalize(make_graph(gnntf, coo, vals, shape), "symmetric")
     rng = np.random.default_rng(C)
     H0 = dev(rng.standard_normal((n, C)).astype(np.float32))
     G = dev(rng.standard_normal((n, C)).astype(np.float32))
     assert sparse.friendly_width(C) > C and sparse.friendly_width(C) % 4 == 0 and sparse.friendly_width(6) == 6 and sparse.friendly_width(64) == 64
+    assert sparse.friendly_width(C, 2708) == C
     results = []
     for pad in (True, False):
         sparse.PAD_WIDTHS = pad
