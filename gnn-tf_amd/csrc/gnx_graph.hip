@@ -212,8 +212,9 @@ void free_csr(Csr &m) {
 
 int build_long_plan(Csr &m, hipStream_t s) {
     m.n_long = 0; m.n_chunks = 0;
-    m.long_row = m.n_rows < SMALL_ROWS ? SMALL_LONG_ROW : LONG_ROW;          // see gnx_internal.h
-    m.long_chunk = m.n_rows < SMALL_ROWS ? SMALL_LONG_ROW : LONG_CHUNK;
+    const bool small = m.n_rows >= TINY_ROWS && m.n_rows < SMALL_ROWS;       // see gnx_internal.h
+    m.long_row = small ? SMALL_LONG_ROW : LONG_ROW;
+    m.long_chunk = small ? SMALL_LONG_ROW : LONG_CHUNK;
     const int order_clamp = m.long_row < 65535 ? m.long_row : 65535;
     if (m.n_rows == 0) return GNX_OK;
     {   // degree-binned row order

@@ -43,9 +43,10 @@ void set_error(const char *fmt, ...);
 constexpr int LONG_ROW = GNX_LONG_ROW;
 constexpr int LONG_CHUNK = GNX_LONG_CHUNK;
 // Small structures (a citation graph: 10^5 rows) are bound by the LATENCY of their longest walk, not by bandwidth: one
-// 512-entry row is 128 dependent gather rounds of a 16-lane group (0.13 ms -- the whole launch).  Below 2^20 rows the plan
-// therefore cuts rows at 128 entries into 128-entry chunks, and the sub-wave kernels take chunks and short rows in one launch.
+// 512-entry row is 128 dependent gather rounds of a 16-lane group (0.13 ms -- the whole launch).  Between 2^15 and
+// 2^20 rows the plan therefore cuts rows at 128 entries into 128-entry chunks, and the sub-wave kernels take chunks and short rows in one launch.
 constexpr int SMALL_ROWS = 1 << 20;
+constexpr int TINY_ROWS = 1 << 15;      // below this everything is cache-resident and launch-bound: an extra reduce launch costs more than it saves
 constexpr int SMALL_LONG_ROW = GNX_LONG_ROW < 128 ? GNX_LONG_ROW : 128;
 
 // One CSR-like structure (the matrix itself, or its transpose).

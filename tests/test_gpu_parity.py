@@ -267,11 +267,13 @@ def test_ppr_step_all_widths(gnntf, C):
     np.testing.assert_allclose(gnntf.spmm(adj, dev(H)).cpu().numpy(), orc.sparse_dense_matmul(ai, av, shape, H), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("n_rows", [700, 40000])
 @pytest.mark.parametrize("C", [7, 64, 256])
-def test_long_rows_and_ragged(gnntf, C):
-    """Hub rows far above LONG_ROW (512) entries, empty rows, a rectangular matrix, ragged tails."""
+def test_long_rows_and_ragged(gnntf, C, n_rows):
+    """Hub rows far above the long-row threshold (512 entries; 128 for structures of 2^15 ... 2^20 rows -- n_rows = 40000 --, where
+    the 513- and 512-entry rows are cut into 128-entry chunks too), empty rows, a rectangular matrix, ragged tails."""
     rng = np.random.default_rng(C)
-    n_rows, n_cols = 700, 5000
+    n_cols = 5000
     hub = np.stack([np.zeros(4999, dtype=np.int64), rng.permutation(n_cols)[:4999]], axis=1)      # one 4999-entry row
     hub2 = np.stack([np.full(513, 3, dtype=np.int64), rng.permutation(n_cols)[:513]], axis=1)      # just over the threshold
     edge = np.stack([np.full(512, 5, dtype=np.int64), rng.permutation(n_cols)[:512]], axis=1)      # exactly at it
