@@ -463,7 +463,7 @@ class ShardedGraph:
     # ---- a block among several: halo plan --------------------------------------------------------------
     def _build_block(self, row, col, nvals, split_rows):
         be, dev, comm = self.backend, self.device, self.comm
-        P, me, n_local, N, lo = self.world, self.rank, self.n_local, self.n_global, self.lo
+        P, me, n_local, lo = self.world, self.rank, self.n_local, self.lo
         bnd = torch.tensor(self.bounds[1:], dtype=torch.int64, device=dev)
         owner = torch.bucketize(col, bnd, right=True)
         remote = owner != me
@@ -625,7 +625,7 @@ class ShardedGraph:
         if iterations == 0:
             state.result.copy_(state.H0)
             return state.result
-        lanes, nc = self._lanes, len(state.cols)
+        lanes = self._lanes
         packed = []
         for c, (c0, c1) in enumerate(state.cols):
             self.local_view(state.bufs[c][0]).copy_(state.H0[:, c0:c1])
