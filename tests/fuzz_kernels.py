@@ -20,13 +20,17 @@ stats = dict(spmm=0, dropped=0, kloop=0, gcnii=0, dense=0, wgrad=0, head=0, edge
 for case in range(cases):
     kind = case % 8
     if kind in (0, 1, 2, 3):
-        n = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 6000]))
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 6000, 33000]))        # 33000: the 128-entry long-row regime (2^15 ... 2^20 rows)
         sq = kind != 0 or rng.random() < 0.5
         n_cols = n if sq else int(rng.integers(1, 2000))
         nnz = int(rng.integers(0, 40 * n + 1))
         idx = np.stack([rng.integers(n, size=nnz), rng.integers(n_cols, size=nnz)], 1).astype(np.int64)
         if nnz > 1200 and rng.random() < 0.6:
             idx[: nnz // 2, 0] = int(rng.integers(n))                          # a hub row: the long-row kernels
+        if nnz > 4000:
+            for k in range(3):                                                   # rows of 130 ... 500 entries: long in one regime, short in the other
+                m = int(rng.integers(130, 500))
+                idx[nnz - (k + 1) * 500: nnz - (k + 1) * 500 + m, 0] = int(rng.integers(n))
         if kind in (1, 2, 3):
             idx = np.unique(idx, axis=0); nnz = len(idx)                          # fused dropout / K loop / GCNII: no duplicates
         vals = (rng.random(nnz) + 0.25).astype(np.float32)
