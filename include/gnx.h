@@ -300,7 +300,9 @@ int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *st
 int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void *stream);
 
 /* Name of the SpMM kernel the last gnx_spmm/_t call on this handle dispatched (static
- * string; for profiles and tests). */
+ * string; for profiles and tests): "spmm_wave", "spmm_group4" ... "spmm_group32" (lanes per row), "..._drop" (weights made
+ * in the kernel), "...+chunks" (structures below 2^20 rows: the chunks of the long rows share the launch of the short rows),
+ * "spmm_gcnii_mfma", "spmm+dense_mfma". */
 const char *gnx_graph_last_kernel(gnx_graph_t g);
 
 #ifdef __cplusplus
