@@ -136,6 +136,23 @@ def main():
     state = sg.make_state(H0)
     t_c = sg.time_compute(state, 0.1)
     t_x = sg.time_exchange(state)                                       # loop-back copies: local HBM traffic only
+
+    def part_ms(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.time() - t0) / reps * 1e3
+    every = range(len(state.cols))
+    src = lambda c: state.bufs[c][0]
+    dst = lambda c: sg.local_view(state.bufs[c][1])
+    breakdown = {
+        "interior_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=True, skip_empty=True) for c in every]),
+        "boundary_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=False, skip_empty=True) for c in every]),
+        "pack": part_ms(lambda: [sg._pack(state, c, state.bufs[c][1]) for c in every]),
+        "first_iterations_interior_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=True, skip_empty=False) for c in every]),
+    }
     sg.propagate(state, 0.1, 10)
     torch.cuda.synchronize()
     t0 = time.time()
@@ -149,7 +166,7 @@ def main():
            "split_rows": bool(sg.split_rows)}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
            "local_entries": sg.nnz_local, "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
            "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
-           "loopback_copy_ms_per_iteration": t_x * 1e3, "step_ms_K10_loopback": t_step * 1e3,
+           "kernels_breakdown_ms": breakdown, "loopback_copy_ms_per_iteration": t_x * 1e3, "step_ms_K10_loopback": t_step * 1e3,
            "predicted_iteration_ms": {f"{bw}_GBs_per_link": max(t_c * 1e3, halo_rows * C * 4 / ((P - 1) * bw * 1e9) * 1e3) for bw in (30, 45, 60, 75)},
            "kernel": sg.graph.last_kernel()}
     print(json.dumps(out, indent=1))
