@@ -238,8 +238,8 @@ def make_grid(world, rank, pv, pf):
 
 def grid_cost_ms(pv, pf, feats, nodes_total, entries_total, link_GBs, halo_frac=0.09):
     """Estimated time of ONE propagation iteration on a pv x pf grid:
-      * compute: entries per rank x (5.5 + 0.61 * max(w, 32)) ps, w = columns per rank -- the fused kernel's
-        measured cost (RMAT 10M/100M: 2.5 / 4.5 / 8.6 / 16.3 ms at w = 32 / 64 / 128 / 256; below 32 columns a
+      * compute: entries per rank x (6 + 0.53 * max(w, 32)) ps, w = columns per rank -- the fused kernel's
+        measured cost (RMAT 10M/100M, round 2: 2.4 / 3.9 / 7.3 / 14.5 ms at w = 32 / 64 / 128 / 256; below 32 columns a
         gather still moves one 128-byte line, so narrower slices are not cheaper);
       * exchange (pv > 1 only): halo_frac * nodes_total rows of 4w bytes arrive per rank over its pv - 1 links
         (one xGMI link per peer, ``link_GBs`` per direction -- a MEASURED figure: bench.py times a pairwise
@@ -247,7 +247,7 @@ def grid_cost_ms(pv, pf, feats, nodes_total, entries_total, link_GBs, halo_frac=
         share of all vertices (graph dependent; ShardedGraph.halo_stats() reports the real one);
       * the two overlap (column chunks), so the iteration costs the larger of them."""
     w = max(feats // pf, 1)
-    compute = entries_total / pv * (5.5 + 0.61 * max(w, 32)) * 1e-9
+    compute = entries_total / pv * (6.0 + 0.53 * max(w, 32)) * 1e-9
     comm = 0.0 if pv == 1 else halo_frac * nodes_total * 4.0 * w / ((pv - 1) * link_GBs * 1e9) * 1e3
     return max(compute, comm)
 
