@@ -940,6 +940,62 @@ class ShardedPPRLoop(Layer):
         return self._propagate("forward", H0.detach())
 
 
+class _BlockSpMM(torch.autograd.Function):
+    """A_hat . X over a vertex block (one halo exchange) as an autograd node; for the symmetric A_hat of an undirected graph the
+    backward is the same product applied to the gradient."""
+
+    @staticmethod
+    def forward(ctx, X, layer):
+        ctx.layer = layer
+        return layer._aggregate("forward", X.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.layer._aggregate("backward", g.contiguous()), None
+
+
+class ShardedGCNLayer(Layer):
+    """GCNLayer (gcn.py:77-89), dropout(activation((A_hat . X) . W + b)), for a model that holds ONE vertex block: the aggregation
+    is one iteration of the vertex-block propagation with a = 0 (pack, pairwise exchange, fused SpMM), the transform acts row by
+    row.  Constant adjacency (graph_dropout = 0, what the reference's GCN uses in eval mode and GCNII always); training needs a
+    symmetric A_hat, like ShardedPPRLoop, and the same SummedGradients / BlockNodeClassification pair."""
+
+    def __build__(self, architecture, graph: "ShardedGraph", outputs: int, activation=None, bias: bool = True, dropout: float = 0,
+                  symmetric: bool = True):
+        from .blocks import relu
+        if architecture.top_shape()[0] != graph.n_local:
+            raise Exception("ShardedGCNLayer: the architecture must hold this rank's %d rows" % graph.n_local)
+        self.graph, self.symmetric = graph, symmetric
+        self.W = architecture.create_var((architecture.top_shape()[1], outputs))
+        self.b = architecture.create_var((1, outputs), "zero") if bias else 0
+        self.activation = relu if activation is None else activation
+        self.dropout = dropout
+        self._states = dict()
+        return (architecture.top_shape()[0], outputs)
+
+    def _aggregate(self, which, X):
+        X = X.to(torch.float32).contiguous()
+        state = self._states.get(which)
+        if state is None or tuple(state.H0.shape) != tuple(X.shape):
+            state = self._states[which] = self.graph.make_state(X.clone())
+        elif self.graph.row_order is not None:
+            state.H0_user.copy_(X)
+            state.H0.copy_(X.index_select(0, self.graph.row_order))
+        else:
+            state.H0.copy_(X)
+        return self.graph.propagate(state, 0.0, 1).clone()            # (1 - 0) A_hat X + 0 * X
+
+    def __forward__(self, architecture, features):
+        from .blocks import affine
+        if torch.is_grad_enabled() and features.requires_grad:
+            if not self.symmetric:
+                raise Exception("ShardedGCNLayer: gradients need a symmetric adjacency (the backward reuses the forward product)")
+            aggregated = _BlockSpMM.apply(features, self)
+        else:
+            aggregated = self._aggregate("forward", features.detach())
+        return architecture.dropout(affine(aggregated, self.W, self.b, self.activation), self.dropout)
+
+
 class SummedGradients:
     """Optimizer wrapper for models that hold one vertex block each: before every step the gradients of the (replicated)
     parameters are summed over the ranks, so every rank applies the same update -- what one process holding all rows would

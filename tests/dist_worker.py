@@ -197,6 +197,60 @@ def train_on_blocks(rank, world, dev, backend, graph_dropout=0.0):
     dist.destroy_process_group()
 
 
+def train_gcn_on_blocks(rank, world, dev, backend):
+    """A 2-layer GCN (gcn.py:108-113: relu on both layers) whose aggregation runs over vertex blocks (ShardedGCNLayer), trained
+    with SummedGradients + BlockNodeClassification, against single-process dense float64 training of the same model."""
+    import gnntf
+    gnntf.set_default_device(dev)
+    n, F, hidden, classes, epochs = 500, 12, 16, 5, 6
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 4000, seed=9)
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    labels = rng.integers(0, classes, size=n)
+    train_ids, valid_ids = np.arange(0, 200), np.arange(200, 350)
+    bounds = sharded.uniform_bounds(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
+    sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend)
+    model = gnntf.Trainable(torch.from_numpy(X[lo:hi]).to(dev))
+    model.add(sharded.ShardedGCNLayer(sg, hidden))
+    model.add(sharded.ShardedGCNLayer(sg, classes))
+    local = lambda ids: ids[(ids >= lo) & (ids < hi)]
+    tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
+    torch.manual_seed(5)
+    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4 / world,
+                optimizer=lambda params: sharded.SummedGradients(torch.optim.Adam(params, lr=0.01, eps=1e-7), sg.comm))
+    got = [v.var.detach().cpu().numpy().astype(np.float64) for v in model.vars()]
+    # ---- one process, dense float64 -------------------------------------------------------------------------------------
+    torch.manual_seed(5)
+    ref = gnntf.Layered((n, F))
+    ref.add(gnntf.Dense(hidden)); ref.add(gnntf.Dense(classes))          # same shapes and initialisers as the GCN layers' variables
+    ref.reset()
+    W1, b1, W2, b2 = [torch.tensor(v.var.detach().cpu().numpy().astype(np.float64), requires_grad=True) for v in ref.vars()]
+    ai, av = orc.get_adjacency(coo, vals, shape, dtype=np.float64)
+    A = torch.from_numpy(orc.to_dense(ai, av, shape, dtype=np.float64))
+    Xt, yt = torch.from_numpy(X.astype(np.float64)), torch.from_numpy(labels)
+    opt = torch.optim.Adam([W1, b1, W2, b2], lr=0.01, eps=1e-7)
+    forward = lambda: torch.relu((A @ torch.relu((A @ Xt) @ W1 + b1)) @ W2 + b2)
+    best, best_params = float("inf"), None
+    for _ in range(epochs):
+        opt.zero_grad()
+        l2 = sum((p ** 2).sum() for p in (W1, b1, W2, b2)) / 2
+        (torch.nn.functional.cross_entropy(forward()[train_ids], yt[train_ids]) + 5e-4 * l2).backward()
+        opt.step()
+        with torch.no_grad():
+            v = float(torch.nn.functional.cross_entropy(forward()[valid_ids], yt[valid_ids]))
+        if v < best:
+            best, best_params = v, [p.detach().clone().numpy() for p in (W1, b1, W2, b2)]
+    for name, g_, w_ in zip(("W1", "b1", "W2", "b2"), got, best_params):
+        np.testing.assert_allclose(g_, w_, rtol=2e-3, atol=2e-5, err_msg=name)
+    gnntf.set_default_device(None)
+    if rank == 0:
+        print("OK gcn world", world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def dropout_on_blocks(rank, world, dev, backend, directed):
     """Training-mode propagation with per-iteration edge dropout on vertex blocks: the masks are keyed by global (row, col),
     so forward and backward must equal the single-process oracle with the same seed, whatever the partition."""
@@ -264,6 +318,9 @@ def main():
     if mode == "train":
         on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
         return train_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())
+    if mode == "gcn":
+        on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
+        return train_gcn_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())
     if mode == "train_dropout":
         on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
         return train_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend(), 0.5)
