@@ -165,6 +165,7 @@ struct SpmmArgs {
     const int32_t *out_rows;   // optional destination row of every result row (gnx_spmm_scatter / gnx_spmm_rows)
     bool map_h0;               // H0 rows are indexed through out_rows as well (gnx_spmm_rows)
     int64_t n_rows;
+    int64_t slot0;             // first row slot of this launch (a launch holds at most 2^32 work-items: huge graphs are dealt in pieces)
     int C;
     // long rows
     const int32_t *long_rows;

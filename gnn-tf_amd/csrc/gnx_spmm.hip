@@ -198,7 +198,7 @@ template <int VEC, int U, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t slot = (int64_t)blockIdx.x * WPB + wib;
+    const int64_t slot = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
     if (slot >= p.n_rows) return;
     const int64_t row = (p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
@@ -221,7 +221,7 @@ template <int VEC, int G, int U, bool PIPE>
 __device__ __forceinline__ void group_rows(const SpmmArgs &p, int64_t block) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
-    const int64_t slot = block * RPB + threadIdx.x / G;
+    const int64_t slot = p.slot0 + block * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;   // degree-binned: the rows of one wave have similar lengths
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
@@ -517,7 +517,7 @@ template <int VEC, int U, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_spmm_wave_drop(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t row = (int64_t)blockIdx.x * WPB + wib;
+    const int64_t row = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
     if (row >= p.n_rows) return;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > p.long_row) return;
@@ -536,7 +536,7 @@ template <int VEC, int G, int U>
 __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
-    const int64_t slot = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+    const int64_t slot = p.slot0 + (int64_t)blockIdx.x * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
@@ -680,11 +680,13 @@ __global__ void k_gather_vals(const float *__restrict__ vals, const int32_t *__r
 // out[r, :] = X[idx[r], :] for int32 row ids, any width (the relabelled K loop permutes H0 once per call)
 __global__ __launch_bounds__(256) void k_gather_rows32(const float *__restrict__ X, int64_t ldx, const int32_t *__restrict__ idx, int64_t n_idx,
                                                         int C, float *__restrict__ out, int64_t ldo) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_idx * C) return;
-    const int64_t r = e / C;
-    const int c = (int)(e % C);
-    out[r * ldo + c] = X[(int64_t)idx[r] * ldx + c];
+    // grid-stride: a launch may not hold more than 2^32 work-items, and n_idx * C can (80M rows x 128 columns)
+    const int64_t total = n_idx * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / C;
+        const int c = (int)(e % C);
+        out[r * ldo + c] = X[(int64_t)idx[r] * ldx + c];
+    }
 }
 
 template <int VEC>
@@ -780,6 +782,20 @@ int pick_vec(const SpmmArgs &p) {
 
 #define GNX_LAUNCH(kern, grid, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, __VA_ARGS__)
 
+// One launch holds at most 2^32 work-items (the dispatch packet's grid size is 32 bits).  A wave per row reaches that at 67M rows,
+// 32 lanes per row at 134M -- sizes a 288 GB card holds -- so the row kernels are dealt in pieces of at most 2^31 work-items
+// (SpmmArgs::slot0 = first row slot of the piece; one piece for everything smaller).
+#define GNX_ROW_PIECES(kern, rows_per_block, threads)                                                                       \
+    do {                                                                                                                    \
+        const int64_t per_launch_ = (((int64_t)1 << 31) / (threads)) * (rows_per_block);                                     \
+        for (int64_t r0_ = 0; r0_ < p.n_rows; r0_ += per_launch_) {                                                          \
+            SpmmArgs q_ = p;                                                                                                \
+            q_.slot0 = r0_;                                                                                                 \
+            const int64_t rows_ = p.n_rows - r0_ < per_launch_ ? p.n_rows - r0_ : per_launch_;                               \
+            hipLaunchKernelGGL(kern, dim3(blocks_for(rows_, rows_per_block)), dim3(threads), 0, s, q_);                      \
+        }                                                                                                                   \
+    } while (0)
+
 template <int VEC>
 const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;  // lanes needed to cover one row
@@ -788,8 +804,8 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
         // degree-ordered rows +9 %, non-temporal H0/out/index loads +-0 %)
         // measured (tools/tune_spmm.py): 8 waves per block are 1.6 % faster than 4 when the row is one tile wide
         // (C = 256), 0.6 % slower at two tiles (C = 512); 2 and 16 waves per block lose 3-11 %
-        if (p.C <= 64 * VEC) hipLaunchKernelGGL((k_spmm_wave<VEC, 8, 8>), dim3(blocks_for(p.n_rows, 8)), dim3(512), 0, s, p);
-        else                 hipLaunchKernelGGL((k_spmm_wave<VEC, 8, 4>), dim3(blocks_for(p.n_rows, 4)), dim3(256), 0, s, p);
+        if (p.C <= 64 * VEC) GNX_ROW_PIECES((k_spmm_wave<VEC, 8, 8>), 8, 512);
+        else                 GNX_ROW_PIECES((k_spmm_wave<VEC, 8, 4>), 4, 256);
         return "spmm_wave";
     }
     // measured (tools/tune_spmm.py, RMAT 10M/100M): prefetching the next (col, val) batch behind the
@@ -798,8 +814,8 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
 #define GNX_GROUP(G, RPB_, PIPE_DEFAULT)                                                              \
     do {                                                                                              \
         const bool pipe = gsel == 2 || (gsel == 0 && PIPE_DEFAULT);                                   \
-        if (pipe) GNX_LAUNCH((k_spmm_group<VEC, G, 4, true>), blocks_for(p.n_rows, RPB_), p);         \
-        else      GNX_LAUNCH((k_spmm_group<VEC, G, 4, false>), blocks_for(p.n_rows, RPB_), p);        \
+        if (pipe) GNX_ROW_PIECES((k_spmm_group<VEC, G, 4, true>), RPB_, 256);                         \
+        else      GNX_ROW_PIECES((k_spmm_group<VEC, G, 4, false>), RPB_, 256);                        \
     } while (0)
     // (round 2, one-process A/B at C = 128 / 64: 8 entries in flight per lane 8.86 / 4.57 ms, pipelined 8.98 / 4.37, 2 entries 8.24 / 4.37
     //  against 8.24 / 4.36 for the shipped 4 -- the sub-wave kernels sit on the bandwidth plateau, not on latency)
@@ -846,14 +862,14 @@ template <int VEC>
 const char *launch_rows_drop(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
     if (lanes > 32) {
-        if (p.C <= 64 * VEC) hipLaunchKernelGGL((k_spmm_wave_drop<VEC, 8, 8>), dim3(blocks_for(p.n_rows, 8)), dim3(512), 0, s, p);
-        else                 hipLaunchKernelGGL((k_spmm_wave_drop<VEC, 8, 4>), dim3(blocks_for(p.n_rows, 4)), dim3(256), 0, s, p);
+        if (p.C <= 64 * VEC) GNX_ROW_PIECES((k_spmm_wave_drop<VEC, 8, 8>), 8, 512);
+        else                 GNX_ROW_PIECES((k_spmm_wave_drop<VEC, 8, 4>), 4, 256);
         return "spmm_wave_drop";
     }
-    if (lanes > 16) { GNX_LAUNCH((k_spmm_group_drop<VEC, 32, 4>), blocks_for(p.n_rows, 8), p); return "spmm_group32_drop"; }
-    if (lanes > 8)  { GNX_LAUNCH((k_spmm_group_drop<VEC, 16, 4>), blocks_for(p.n_rows, 16), p); return "spmm_group16_drop"; }
-    if (lanes > 4)  { GNX_LAUNCH((k_spmm_group_drop<VEC, 8, 4>), blocks_for(p.n_rows, 32), p); return "spmm_group8_drop"; }
-    GNX_LAUNCH((k_spmm_group_drop<VEC, 4, 4>), blocks_for(p.n_rows, 64), p);
+    if (lanes > 16) { GNX_ROW_PIECES((k_spmm_group_drop<VEC, 32, 4>), 8, 256); return "spmm_group32_drop"; }
+    if (lanes > 8)  { GNX_ROW_PIECES((k_spmm_group_drop<VEC, 16, 4>), 16, 256); return "spmm_group16_drop"; }
+    if (lanes > 4)  { GNX_ROW_PIECES((k_spmm_group_drop<VEC, 8, 4>), 32, 256); return "spmm_group8_drop"; }
+    GNX_ROW_PIECES((k_spmm_group_drop<VEC, 4, 4>), 64, 256);
     return "spmm_group4_drop";
 }
 
@@ -1129,7 +1145,8 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
         if (rc != GNX_OK) return rc;
         hipLaunchKernelGGL(k_gather_vals, dim3(blocks_for(g->a.nnz, 256)), dim3(256), 0, s, d_vals ? d_vals : g->raw_vals, g->r_perm, g->a.nnz,
                            g->r_vals);
-        hipLaunchKernelGGL(k_gather_rows32, dim3(blocks_for(n * C, 256)), dim3(256), 0, s, d_H0, C, g->a.row_order, n, (int)C, g->r_feat, C);
+        hipLaunchKernelGGL(k_gather_rows32, dim3((unsigned)std::min<int64_t>(blocks_for(n * C, 256), 1 << 22)), dim3(256), 0, s, d_H0, C,
+                           g->a.row_order, n, (int)C, g->r_feat, C);
         const float *src = g->r_feat;
         for (int k = 0; k < K; ++k) {
             const bool last = k == K - 1;
