@@ -1216,6 +1216,7 @@ int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void 
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C, float *d_out, int64_t ldo,
                     void *stream) {
     GNX_CHECK_ARG(n_idx >= 0 && C >= 1 && ldx >= C && ldo >= C, "gnx_gather_rows: bad sizes");
+    GNX_CHECK_ARG(n_idx < ((int64_t)1 << 26), "gnx_gather_rows: at most 2^26 - 1 rows per call (one wave per row, 2^32 work-items per launch)");
     if (n_idx == 0) return GNX_OK;
     GNX_CHECK_ARG(d_X && d_idx && d_out, "gnx_gather_rows: NULL pointer");
     hipStream_t s = (hipStream_t)stream;

@@ -324,7 +324,10 @@ def max_relative_deviation(got, want, rows_per_pass=1 << 22):
     worst = 0.0
     for r0 in range(0, got.shape[0], rows_per_pass):
         g, w = got[r0:r0 + rows_per_pass], want[r0:r0 + rows_per_pass]
-        worst = max(worst, float(((g - w).abs() / w.abs().clamp_min(1.0)).max()))
+        d = float(((g - w).abs() / w.abs().clamp_min(1.0)).max())
+        if d != d:                                   # a NaN anywhere is a failure, not a value max() may skip
+            return float("inf")
+        worst = max(worst, d)
     return worst
 
 

@@ -97,6 +97,29 @@ def test_config5_full_size_eigenvector(gnntf):
     torch.cuda.empty_cache()
 
 
+def test_more_rows_than_one_launch_holds(gnntf):
+    """68M rows at C = 256 is one WAVE per row = 4.35e9 work-items, more than the 2^32 a single dispatch may hold: the row kernels
+    are dealt in pieces (SpmmArgs::slot0).  One fused step on the fixed point sqrt(deg) x s must return it, on every row --
+    before the pieces existed the launch was rejected and the output left untouched."""
+    import bench
+    from gnntf.sharded import max_relative_deviation
+    from gnntf.sparse import _launch
+    n, C = 68_000_000, 256
+    g, adj, _ = bench.build_single(argparse.Namespace(nodes=n, entries=136_000_000), torch.device("cuda:0"))
+    deg = torch.empty(n, dtype=torch.float32, device="cuda")
+    from gnntf import _native as nat
+    nat.check(nat.lib().gnx_graph_colsum(g.handle, 0.0, 0, 0, nat.ptr(deg), nat.current_stream()))
+    s = 0.5 + torch.arange(C, device="cuda", dtype=torch.float32) / C
+    H0 = deg.sqrt().unsqueeze(1) * s.unsqueeze(0)
+    out = torch.full_like(H0, float("nan"))
+    _launch(adj, H0, H0, 0.9, 0.1, 0, out=out)
+    assert g.last_kernel() == "spmm_wave"
+    assert max_relative_deviation(out, H0) < 1e-5                    # (NaN anywhere would fail the comparison)
+    assert bool(torch.isfinite(out[-1000:]).all()) and bool(torch.isfinite(out[:1000]).all())
+    del out, H0, g, adj
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("world,cover,n,entries,C", [(8, "cover", 8_000_000, 100_000_000, 128), (4, "pull", 2_000_000, 24_000_000, 64),
                                                      (3, "cover", 1_000_003, 12_000_000, 40)])
 def test_vertex_blocks_of_one_graph_match_one_gpu(gnntf, world, cover, n, entries, C):
