@@ -367,6 +367,8 @@ class ShardState:
 class ShardedGraph:
     """This rank's block of a symmetrically normalised, vertex-partitioned square graph."""
 
+    MIN_INTERIOR_SHARE = 0.05      # share of a block's entries that must sit in interior rows for the interior / boundary split to pay
+
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
                  relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
@@ -374,7 +376,7 @@ class ShardedGraph:
         vertex partition (``comm`` / ``group``) must call it with the same options.
         ``cover``: "cover" (pull/push vertex cover, default) or "pull" (classic halo; bitwise the one-GPU sums).
         ``split_rows``: interior rows (no remote column) as a handle of their own, computed before the halo is
-        waited for.  ``chunks``: independent column chunks whose exchange and SpMM overlap (default 2).
+        waited for -- when they hold at least MIN_INTERIOR_SHARE of the block's entries ("always": whatever they hold).  ``chunks``: independent column chunks whose exchange and SpMM overlap (default 2).
         ``keep_entries``: keep (global row, global col, normalised value, pushed?) of this rank's entries in
         ``self.entries`` (tests).  ``relabel`` (single vertex block only): store the shard with its vertices relabelled in stable order of
         descending entry count -- a legal preprocessing step that makes the sub-wave kernels
@@ -555,9 +557,12 @@ class ShardedGraph:
 
         # ---- the main CSR over X; interior rows (no remote column: their sums need no halo) apart -------------
         n_bnd = int(is_bnd.sum())
-        self.split_rows = bool(split_rows) and 0 < n_bnd < n_local
+        sel = is_bnd[m_rows]
+        # interior rows in a handle of their own only when they hold real work to put under the exchange: on a randomly
+        # partitioned power-law graph they are almost all isolated vertices, and a launch that finds nothing to do is pure cost
+        interior_share = 1.0 - float(sel.sum()) / max(int(sel.numel()), 1)
+        self.split_rows = 0 < n_bnd < n_local and (split_rows == "always" or (bool(split_rows) and interior_share >= self.MIN_INTERIOR_SHARE))
         if self.split_rows:
-            sel = is_bnd[m_rows]
             rank_b = torch.cumsum(is_bnd.to(torch.int64), 0) - 1
             rank_i = torch.cumsum((~is_bnd).to(torch.int64), 0) - 1
             self.rows_bnd = torch.nonzero(is_bnd).reshape(-1).to(torch.int32)
