@@ -626,17 +626,22 @@ class ShardedGraph:
         else:
             self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out, rows=self.rows_bnd, skip_empty=skip_empty)
 
-    def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10):
-        """H <- H0, then K iterations; returns this rank's rows of the result (in the caller's vertex order)."""
+    def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10, start=None):
+        """H <- H0 (or ``start``: this rank's rows of another initial H, e.g. the input of a GCNII layer whose mix term is
+        H0), then K iterations of H <- (1-a) A_hat H + a H0; returns this rank's rows of the result (in the caller's vertex
+        order)."""
+        if start is not None and tuple(start.shape) != tuple(state.H0_user.shape if self.row_order is not None else state.H0.shape):
+            raise Exception("propagate: start must have the shape of H0")
         if self.world == 1:
-            return self._propagate_single_block(state, a, iterations)
+            return self._propagate_single_block(state, a, iterations, start)
+        first = state.H0 if start is None else start
         if iterations == 0:
-            state.result.copy_(state.H0)
+            state.result.copy_(first)
             return state.result
         lanes = self._lanes
         packed = []
         for c, (c0, c1) in enumerate(state.cols):
-            self.local_view(state.bufs[c][0]).copy_(state.H0[:, c0:c1])
+            self.local_view(state.bufs[c][0]).copy_(first[:, c0:c1])
             self._pack(state, c, state.bufs[c][0])
             packed.append(lanes.mark())
         for k in range(iterations):
@@ -659,13 +664,15 @@ class ShardedGraph:
                     packed[c] = lanes.mark()
         return state.result
 
-    def _propagate_single_block(self, state, a, iterations):
+    def _propagate_single_block(self, state, a, iterations, start=None):
         # no exchange; the first iteration reads H0 in place, and on a relabelled shard the last one scatters its
         # rows straight back into the caller's order
         if iterations == 0:
-            return state.H0_user if self.row_order is not None else state.H0
+            return start if start is not None else (state.H0_user if self.row_order is not None else state.H0)
         state.cur = 0
         src = state.H0
+        if start is not None:
+            src = start.to(torch.float32).contiguous() if self.row_order is None else start.to(torch.float32).index_select(0, self.row_order)
         for k in range(iterations):
             last = k == iterations - 1
             if last and self.row_order is not None:
@@ -1002,6 +1009,71 @@ class ShardedGCNLayer(Layer):
         else:
             aggregated = self._aggregate("forward", features.detach())
         return architecture.dropout(affine(aggregated, self.W, self.b, self.activation), self.dropout)
+
+
+class _BlockMixStep(torch.autograd.Function):
+    """(1-a) A_hat H + a H0 over a vertex block with H and H0 distinct (the aggregation of a GCNII layer); symmetric A_hat:
+    dH = (1-a) A_hat g -- the same step applied to g with a zero mix term -- and dH0 = a g."""
+
+    @staticmethod
+    def forward(ctx, H, H0, layer):
+        ctx.layer = layer
+        return layer._step("forward", H.detach(), H0.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gH = ctx.layer._step("backward", g, torch.zeros_like(g)) if ctx.needs_input_grad[0] else None
+        gH0 = g * ctx.layer.a if ctx.needs_input_grad[1] else None
+        return gH, gH0, None
+
+
+class ShardedGCNIILayer(Layer):
+    """GCNIILayer (gcn.py:7-27), dropout(act(((1-a) A_hat H + a H0) . ((1-b) I + b W))), b = beta_transformer(l / (k+1)), for a
+    model that holds ONE vertex block: the aggregation is one iteration of the vertex-block propagation started from this
+    layer's input with H0's value as the mix term; the C x C transform acts row by row.  Constant adjacency (graph_dropout = 0);
+    gradients need a symmetric A_hat, as for the other block layers."""
+
+    def __build__(self, architecture, graph: "ShardedGraph", H0: Layer, a: float, l: float, k: int = 0, activation=None,
+                  beta_transformer=None, dropout: float = 0.5, regularization=True, symmetric: bool = True):
+        import math
+        from .blocks import linear
+        if architecture.top_shape()[0] != graph.n_local:
+            raise Exception("ShardedGCNIILayer: the architecture must hold this rank's %d rows" % graph.n_local)
+        width = architecture.top_shape()[1]
+        self.W = architecture.create_var((width, width), "zero", regularize=regularization)
+        self.graph, self.H0, self.a, self.l, self.k, self.symmetric = graph, H0, a, l, k, symmetric
+        self.activation = linear if activation is None else activation
+        self.beta_transformer = math.log1p if beta_transformer is None else beta_transformer
+        self.dropout = dropout
+        self._states = dict()
+        return architecture.top_shape()
+
+    def _step(self, which, H, H0):
+        H0 = H0.to(torch.float32).contiguous()
+        state = self._states.get(which)
+        if state is None or tuple(state.H0.shape) != tuple(H0.shape):
+            state = self._states[which] = self.graph.make_state(H0.clone())
+        elif self.graph.row_order is not None:
+            state.H0_user.copy_(H0)
+            state.H0.copy_(H0.index_select(0, self.graph.row_order))
+        else:
+            state.H0.copy_(H0)
+        return self.graph.propagate(state, self.a, 1, start=H.to(torch.float32).contiguous()).clone()
+
+    def __forward__(self, architecture, features):
+        b = self.beta_transformer(self.l / (self.k + 1))
+        eye = torch.eye(self.W.shape[1], device=self.W.device, dtype=self.W.dtype)
+        transform = (1 - b) * eye + b * self.W
+        H0 = self.H0.value
+        if torch.is_grad_enabled() and (features.requires_grad or H0.requires_grad):
+            if not self.symmetric:
+                raise Exception("ShardedGCNIILayer: gradients need a symmetric adjacency (the backward reuses the forward product)")
+            tradeoff = _BlockMixStep.apply(features, H0, self)
+        else:
+            tradeoff = self._step("forward", features.detach(), H0.detach())
+        return architecture.dropout(self.activation(sparse.dense(tradeoff, transform) if tradeoff.is_cuda else torch.matmul(tradeoff, transform)),
+                                    self.dropout)
 
 
 class SummedGradients:

@@ -251,6 +251,75 @@ def train_gcn_on_blocks(rank, world, dev, backend):
     dist.destroy_process_group()
 
 
+def train_gcnii_on_blocks(rank, world, dev, backend):
+    """Dense -> 3 GCNII layers (gcn.py:7-27; aggregation over vertex blocks, ShardedGCNIILayer) -> Dense, trained on blocks, against
+    single-process dense float64 training of the same model."""
+    import math
+    import gnntf
+    gnntf.set_default_device(dev)
+    n, F, hidden, classes, layers, a, l, epochs = 480, 10, 16, 4, 3, 0.1, 0.5, 6
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 3600, seed=4)
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    labels = rng.integers(0, classes, size=n)
+    train_ids, valid_ids = np.arange(0, 200), np.arange(200, 340)
+    bounds = sharded.uniform_bounds(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = (coo[:, 0] >= lo) & (coo[:, 0] < hi)
+    sg = sharded.ShardedGraph(torch.from_numpy(coo[mine]).to(dev), torch.from_numpy(vals[mine]).to(dev), bounds, backend=backend)
+    model = gnntf.Trainable(torch.from_numpy(X[lo:hi]).to(dev))
+    H0 = model.add(gnntf.Dense(hidden, activation=gnntf.relu))
+    for k in range(layers):
+        model.add(sharded.ShardedGCNIILayer(sg, H0, a, l, k, activation=gnntf.relu, dropout=0))
+    model.add(gnntf.Dense(classes))
+    local = lambda ids: ids[(ids >= lo) & (ids < hi)]
+    tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
+    torch.manual_seed(6)
+    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4 / world,
+                optimizer=lambda params: sharded.SummedGradients(torch.optim.Adam(params, lr=0.01, eps=1e-7), sg.comm))
+    got = [v.var.detach().cpu().numpy().astype(np.float64) for v in model.vars()]
+    # ---- one process, dense float64 -------------------------------------------------------------------------------------
+    torch.manual_seed(6)
+    ref = gnntf.Layered((n, F))
+    ref.add(gnntf.Dense(hidden)); ref.add(gnntf.Dense(classes))
+    ref.reset()
+    Wi, bi, Wo, bo = [torch.tensor(v.var.detach().cpu().numpy().astype(np.float64), requires_grad=True) for v in ref.vars()]
+    Ws = [torch.zeros((hidden, hidden), dtype=torch.float64, requires_grad=True) for _ in range(layers)]
+    params = [Wi, bi] + Ws + [Wo, bo]                       # the order model.vars() registers them in
+    ai, av = orc.get_adjacency(coo, vals, shape, dtype=np.float64)
+    A = torch.from_numpy(orc.to_dense(ai, av, shape, dtype=np.float64))
+    Xt, yt = torch.from_numpy(X.astype(np.float64)), torch.from_numpy(labels)
+    opt = torch.optim.Adam(params, lr=0.01, eps=1e-7)
+
+    def forward():
+        h0 = torch.relu(Xt @ Wi + bi)
+        h = h0
+        for k, W in enumerate(Ws):
+            b = math.log1p(l / (k + 1))
+            h = torch.relu(((1 - a) * (A @ h) + a * h0) @ ((1 - b) * torch.eye(hidden, dtype=torch.float64) + b * W))
+        return h @ Wo + bo
+    best, best_params = float("inf"), None
+    for _ in range(epochs):
+        opt.zero_grad()
+        l2 = sum((p ** 2).sum() for p in params) / 2
+        (torch.nn.functional.cross_entropy(forward()[train_ids], yt[train_ids]) + 5e-4 * l2).backward()
+        opt.step()
+        with torch.no_grad():
+            v = float(torch.nn.functional.cross_entropy(forward()[valid_ids], yt[valid_ids]))
+        if v < best:
+            best, best_params = v, [p.detach().clone().numpy() for p in params]
+    assert len(got) == len(best_params)
+    for i, (g_, w_) in enumerate(zip(got, best_params)):
+        assert g_.shape == w_.shape, (i, g_.shape, w_.shape)
+        np.testing.assert_allclose(g_, w_, rtol=2e-3, atol=2e-5, err_msg="parameter %d" % i)
+    assert max(float(np.abs(w).max()) for w in got[2:2 + layers]) > 1e-3      # the GCNII transforms did move away from zero
+    gnntf.set_default_device(None)
+    if rank == 0:
+        print("OK gcnii world", world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def dropout_on_blocks(rank, world, dev, backend, directed):
     """Training-mode propagation with per-iteration edge dropout on vertex blocks: the masks are keyed by global (row, col),
     so forward and backward must equal the single-process oracle with the same seed, whatever the partition."""
@@ -318,6 +387,9 @@ def main():
     if mode == "train":
         on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
         return train_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())
+    if mode == "gcnii":
+        on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
+        return train_gcnii_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())
     if mode == "gcn":
         on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"
         return train_gcn_on_blocks(rank, world, torch.device("cuda:0" if on_gpu else "cpu"), None if on_gpu else OracleBackend())

@@ -86,6 +86,13 @@ def test_gcn_on_vertex_blocks(world):
     launch(world, "gcn")
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_gcnii_on_vertex_blocks(world):
+    """GCNIILayer (gcn.py:7-27) over vertex blocks: the aggregation (1-a) A_hat H + a H0 with H != H0 is one iteration of the
+    block propagation started from the layer's input; three layers + the two dense ends, trained, against dense float64."""
+    launch(world, "gcnii")
+
+
 @pytest.mark.parametrize("world,cover", [(5, "cover"), (7, "pull")])
 def test_blocks_as_threads_of_one_process(world, cover):
     """The ranks as threads exchanging through shared memory (tests/thread_comm.py, the harness of the GPU full-size block test):
@@ -154,7 +161,7 @@ def test_cover_push_mask_properties():
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode,options", [("slices", "cover,split,2"), ("slices", "pull,whole,1"), ("blocks", "cover,split,2"),
                                           ("rmat", "cover,whole,2"), ("grid1x2", "cover,split,2"), ("train", "cover,split,2"),
-                                          ("dropout", "-"), ("dropout_directed", "-"), ("train_dropout", "-"), ("gcn", "-")])
+                                          ("dropout", "-"), ("dropout_directed", "-"), ("train_dropout", "-"), ("gcn", "-"), ("gcnii", "-")])
 def test_sharded_native_backend_two_ranks_one_gpu(mode, options):
     """The libgnx.so backend on real shards (rectangular CSR over [regions | local | regions], interior / boundary
     handles with row maps, the send CSR, exchange on its own stream): two ranks share cuda:0 and exchange over gloo
