@@ -55,14 +55,20 @@ def main():
                 per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 per[k]["ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     total = 0.0
+    # one propagation iteration = one dispatch of every kernel, except that the row kernel of a very large graph is dealt in
+    # pieces (several dispatches per iteration): the iteration count is the smallest dispatch count among the SpMM kernels, and
+    # every kernel's bytes are its SUM over the run divided by that count
+    iterations = min(len(c["FETCH_SIZE"]) for c in per.values() if c["FETCH_SIZE"])
     with open(os.path.join(HERE, f"{tag}_pmc.csv"), "w") as f:
-        f.write("kernel,dispatches,avg_ms,FETCH_SIZE_KiB_raw,WRITE_SIZE_KiB,hbm_read_bytes_corrected(x2),hbm_write_bytes,hbm_bytes\n")
+        f.write("kernel,dispatches,dispatches_per_iteration,avg_ms,FETCH_SIZE_KiB_raw_per_iteration,WRITE_SIZE_KiB_per_iteration,"
+                "hbm_read_bytes_corrected(x2),hbm_write_bytes,hbm_bytes\n")
         for k, c in sorted(per.items()):
-            fetch = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)
-            write = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+            fetch = sum(c["FETCH_SIZE"]) / iterations
+            write = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]) / max(len(c["FETCH_SIZE"]), 1), 1) / iterations
             rd, wr = 2 * fetch * 1024, write * 1024
             total += rd + wr
-            f.write(f"\"{k}\",{len(c['FETCH_SIZE'])},{sum(c['ms'])/len(c['ms']):.4f},{fetch:.1f},{write:.1f},{rd:.4e},{wr:.4e},{rd+wr:.4e}\n")
+            f.write(f"\"{k}\",{len(c['FETCH_SIZE'])},{len(c['FETCH_SIZE']) / iterations:g},{sum(c['ms'])/len(c['ms']):.4f},{fetch:.1f},{write:.1f},"
+                    f"{rd:.4e},{wr:.4e},{rd+wr:.4e}\n")
     path = os.path.join(HERE, "pmc_traffic.json")
     rec = json.load(open(path)) if os.path.exists(path) else {"workloads": {}}
     rec.setdefault("workloads", {})[workload] = {"fabric_bytes_per_launch": total, "source": f"{tag}_pmc.csv"}
