@@ -137,6 +137,7 @@ struct DropFuse {
     uint32_t thr;          // keep iff hash >= thr
     float scale;           // 1 / (1 - p)
     int transposed;        // the structure walked is the transpose: its entry (r, c) is A[c][r]
+    int col_prescaled;     // the gathered rows already carry their column's scale (written by the previous iteration's epilogue)
     int64_t row0_key, row0_D;   // vertex block: global id of row 0 / position of row 0's scale in D (0, 0 otherwise)
     const int32_t *gid;         // vertex block: global id of every column (null: the column index itself)
 };
@@ -146,7 +147,8 @@ __device__ __forceinline__ float dropped_weight(const DropFuse &f, float raw, in
     const uint64_t stream = f.stream + (f.offset ? *f.offset : 0);
     const uint64_t kc = f.gid ? (uint64_t)f.gid[ac] : (uint64_t)ac;
     if (hash_u24(f.seed, stream, (uint64_t)(ar + f.row0_key), kc, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
-    return (f.D[ar + f.row0_D] * (raw * f.scale)) * f.D[ac];
+    const float w = f.D[ar + f.row0_D] * (raw * f.scale);
+    return f.col_prescaled ? w : w * f.D[ac];
 }
 
 struct SpmmArgs {
@@ -164,6 +166,7 @@ struct SpmmArgs {
     int64_t ldo;
     const int32_t *out_rows;   // optional destination row of every result row (gnx_spmm_scatter / gnx_spmm_rows)
     bool map_h0;               // H0 rows are indexed through out_rows as well (gnx_spmm_rows)
+    const float *out_scale;    // optional per-row factor applied to the finished row (gnx_spmm_dropped_chained: the NEXT iteration's column scale)
     int64_t n_rows;
     int64_t slot0;             // first row slot of this launch (a launch holds at most 2^32 work-items: huge graphs are dealt in pieces)
     int C;

@@ -188,6 +188,11 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
 #pragma unroll
         for (int v = 0; v < VEC; ++v) o[v] = fmaxf(o[v], 0.f);
     }
+    if (p.out_scale) {
+        const float os = p.out_scale[row];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o[v] *= os;
+    }
     if (nt) vstore_nt<VEC>(p.out + orow * p.ldo + c, o);
     else vstore<VEC>(p.out + orow * p.ldo + c, o);
 }
@@ -1039,6 +1044,33 @@ int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t 
     p.fuse.transposed = transposed ? 1 : 0;
     p.fuse.row0_key = g->blk_row0_global; p.fuse.row0_D = g->blk_row0_buf; p.fuse.gid = g->blk_col_gid;
     return launch_spmm(g, transposed ? g->t : g->a, p, s);
+}
+
+int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int x_prescaled,
+                             const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0, float beta,
+                             float alpha, int act, float *d_out, int64_t ldo, void *stream) {
+    int rc = check_common("gnx_spmm_dropped_chained", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_dropped_chained: invalid activation %d", act);
+    GNX_CHECK_ARG(d_D != nullptr, "gnx_spmm_dropped_chained: NULL degree scales");
+    GNX_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout rate %g outside [0, 1)", (double)dropout_p);
+    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols || g->blk_col_gid != nullptr, "gnx_spmm_dropped_chained: needs a square graph or a vertex block");
+    if (g->has_dups) {
+        set_error("gnx_spmm_dropped_chained: the graph holds duplicate COO entries");
+        return GNX_ERR_UNSUPPORTED;
+    }
+    SpmmArgs p{};
+    p.vals = g->raw_vals;
+    p.X = d_X; p.ldx = ldx; p.H0 = d_H0; p.ldh0 = ldh0; p.beta = beta; p.alpha = alpha; p.act = act;
+    p.out = d_out; p.ldo = ldo; p.C = (int)C;
+    p.out_scale = d_D_next ? d_D_next + g->blk_row0_buf : nullptr;
+    p.fuse.D = d_D; p.fuse.seed = seed; p.fuse.stream = stream_id; p.fuse.offset = g->stream_offset;
+    p.fuse.thr = (uint32_t)((double)dropout_p * 16777216.0);
+    p.fuse.scale = 1.0f / (1.0f - dropout_p);
+    p.fuse.transposed = 0;
+    p.fuse.col_prescaled = x_prescaled ? 1 : 0;
+    p.fuse.row0_key = g->blk_row0_global; p.fuse.row0_D = g->blk_row0_buf; p.fuse.gid = g->blk_col_gid;
+    return launch_spmm(g, g->a, p, (hipStream_t)stream);
 }
 
 int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream) {

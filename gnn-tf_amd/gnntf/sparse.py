@@ -285,6 +285,23 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
     return out
 
 
+def _launch_chained(adj: "DroppedAdjacency", X, H0, beta, alpha, prescaled, D_next):
+    """One forward training iteration inside a loop (gnx_spmm_dropped_chained): X carries its column scale when ``prescaled``,
+    the result carries ``D_next`` (the next iteration's column scale) unless that is None."""
+    g = adj.graph
+    nat.require_cuda(X, H0)
+    _same_device(g, X, H0, adj.D, D_next)
+    if X.shape[0] != g.n_cols or tuple(H0.shape) != (g.n_rows, X.shape[1]) or not X.is_contiguous() or not H0.is_contiguous():
+        raise Exception("chained propagation: bad operand shapes")
+    out = torch.empty((g.n_rows, X.shape[1]), dtype=torch.float32, device=X.device)
+    with nat.on_device(X.device):
+        nat.check(nat.lib().gnx_spmm_dropped_chained(g.handle, nat.ptr(adj.D), adj.p, adj.seed, adj.stream_id, 1 if prescaled else 0,
+                                                     nat.ptr(D_next), nat.ptr(X), X.stride(0), X.shape[1], nat.ptr(H0), H0.stride(0),
+                                                     float(beta), float(alpha), nat.ACT_NONE, nat.ptr(out), out.stride(0),
+                                                     nat.current_stream()))
+    return out
+
+
 def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out, act=nat.ACT_NONE):
     """The fused step over a graph that holds a SUBSET of the output rows (the interior or the boundary rows of
     a vertex block): result row r is written to out[rows[r]] and mixes in H0[rows[r]] (gnx_spmm_rows)."""
@@ -382,8 +399,20 @@ class _PPRLoop(torch.autograd.Function):
         ctx.C = C = H0.shape[1]
         H0 = _padded(H0, friendly_width(C, H0.shape[0]))
         H = H0
-        for k in range(K):
-            H = _launch(make_adj(k, False), H, H0, 1.0 - a, a, nat.ACT_NONE)
+        first = make_adj(0, False) if K > 0 else None
+        if K > 1 and isinstance(first, DroppedAdjacency):
+            # weights made in the kernels (only the K degree-scale vectors exist): the next iteration's column scale rides out with
+            # the rows, so from k = 1 on no per-entry scale gather is left (gnx_spmm_dropped_chained)
+            adjs = [first] + [make_adj(k, False) for k in range(1, K)]
+            chained = all(isinstance(adj, DroppedAdjacency) and adj.graph is first.graph for adj in adjs)
+            for k, adj in enumerate(adjs):
+                if chained:
+                    H = _launch_chained(adj, H, H0, 1.0 - a, a, prescaled=k > 0, D_next=adjs[k + 1].D if k + 1 < K else None)
+                else:
+                    H = _launch(adj, H, H0, 1.0 - a, a, nat.ACT_NONE)
+        else:
+            for k in range(K):           # one adjacency alive at a time (a materialised one is an nnz-sized array)
+                H = _launch(first if k == 0 else make_adj(k, False), H, H0, 1.0 - a, a, nat.ACT_NONE)
         return H if H.shape[1] == C else H[:, :C].contiguous()
 
     @staticmethod

@@ -184,6 +184,17 @@ int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t 
                      const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0, float beta, float alpha,
                      int act, float *d_out, int64_t ldo, void *stream);
 
+/* gnx_spmm_dropped_chained: the forward gnx_spmm_dropped for a LOOP of training iterations.  The weight of an entry needs its
+ * column's degree scale, a random 4-byte gather per entry (0.7 of the 3.8 ms of a launch at C = 64); in a loop the previous
+ * iteration can deliver it with the row instead: with d_D_next != NULL every finished row is multiplied by d_D_next[row]
+ * (= the NEXT iteration's scale of that vertex as a column) on its way out, and with x_prescaled != 0 the kernel takes the rows
+ * of d_X as carrying their column scale already.  Iteration 0 runs with x_prescaled = 0, the last one with d_D_next = NULL; the
+ * H0 mix term is the plain one throughout.  Same masks and the same value as K gnx_spmm_dropped calls up to float32 rounding
+ * (the scale is applied to the gathered row instead of the weight). */
+int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int x_prescaled,
+                             const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0,
+                             float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream);
+
 /* gnx_spmm_rows: the fused step for a handle that holds only a SUBSET of the output rows (the interior or the
  * boundary rows of a vertex block, compacted): result row r lands in out[d_rows[r], :] and mixes in
  * H0[d_rows[r], :] (d_rows int32 [n_rows of the handle]; out and H0 are the full-height matrices).  Same

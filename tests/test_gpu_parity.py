@@ -749,3 +749,34 @@ def test_fused_loops_pad_odd_widths(gnntf, C):
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-6)
     want = orc.appnp_propagate(coo, vals, shape, H0.cpu().numpy(), a=0.1, iterations=10)
     np.testing.assert_allclose(results[0][0].cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("C", [8, 64, 256])
+def test_chained_training_forward_equals_step_loop(gnntf, C):
+    """gnx_spmm_dropped_chained: in the fused training loop every epilogue hands the next iteration its column scale with the row
+    (no per-entry scale gather from the second iteration on).  Same masks, same value as K separate gnx_spmm_dropped steps up to
+    float32 rounding -- hub rows, isolated vertices (their scale is 0) and a weighted, value-asymmetric matrix included."""
+    from gnntf import sparse
+    from gnntf.sparse import _launch
+    n, K, a, p_drop, seed, first = 2500, 5, 0.1, 0.5, 9, 4
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 30000, seed=11)
+    hub = np.random.default_rng(1).choice(np.arange(1, n), size=1300, replace=False)
+    coo = np.unique(np.concatenate([coo, np.stack([np.zeros_like(hub), hub], 1), np.stack([hub, np.zeros_like(hub)], 1)]), axis=0)
+    vals = (np.random.default_rng(2).random(len(coo)) + 0.5).astype(np.float32)
+    g = make_graph(gnntf, coo, vals, shape)
+    H0 = dev(np.random.default_rng(C).standard_normal((n, C)).astype(np.float32))
+    D = sparse.dropped_degree_scales(g, p_drop, seed, first, K)
+    make = lambda k, bwd=False: sparse.dropped_adjacency(g, p_drop, seed, first + k, D=D[k])
+    with torch.no_grad():
+        got = sparse.ppr_loop(make, H0, a, K)
+        want = H0
+        for k in range(K):
+            want = _launch(make(k), want, H0, 1.0 - a, a, 0)
+    assert g.last_kernel().endswith("_drop")
+    scale = want.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)
+    assert ((got - want).abs() / scale).max().item() < 2e-5
+    adjs = [orc.get_adjacency(coo, vals, shape, graph_dropout=p_drop, training=True, seed=seed, stream=first + k, dtype=np.float64) for k in range(K)]
+    ref = H0.cpu().numpy().astype(np.float64)
+    for ai, av in adjs:
+        ref = orc.ppr_iteration(ai, av, shape, ref, H0.cpu().numpy().astype(np.float64), a)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
