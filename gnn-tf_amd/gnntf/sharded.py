@@ -118,6 +118,15 @@ class NativeBackend:
         adj = sparse.DroppedAdjacency(graph, p, seed, stream_id, D=D)
         sparse._launch(adj, X, H0, beta, alpha, nat.ACT_NONE, transposed=bool(transposed), out=out)
 
+    def spmm_dropped_chained(self, graph, D, p, seed, stream_id, prescaled, D_next, X, H0, beta, alpha, out):
+        """The forward spmm_dropped inside a loop: X carries its column scale when ``prescaled``; the result rows carry
+        ``D_next`` (the next iteration's scale of every buffer column; row r's own entry is used) unless it is None."""
+        with nat.on_device(graph.device):
+            nat.check(nat.lib().gnx_spmm_dropped_chained(graph.handle, nat.ptr(D), float(p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                         int(stream_id) & 0xFFFFFFFFFFFFFFFF, 1 if prescaled else 0, nat.ptr(D_next),
+                                                         nat.ptr(X), X.stride(0), X.shape[1], nat.ptr(H0), H0.stride(0), float(beta),
+                                                         float(alpha), nat.ACT_NONE, nat.ptr(out), out.stride(0), nat.current_stream()))
+
     def spmm_t_mix(self, graph, X, H0, beta, alpha, out):
         """out = beta * (A^T X) + alpha * H0 over the graph's own (raw) values."""
         adj = getattr(graph, "_plain_adjacency", None)
@@ -742,11 +751,14 @@ class ShardedGraph:
         be = self.backend
         H0 = H0.to(torch.float32).contiguous()
         C, dev = H0.shape[1], H0.device
+        # every epilogue hands the NEXT iteration its column scale with the row (gnx_spmm_dropped_chained): the scale is a global
+        # per-vertex quantity, so the rows a peer pulls arrive pre-scaled as well
+        nxt = lambda k: scales[k + 1] if k + 1 < iterations else None
         if self.world == 1:
             H = H0
             for k in range(iterations):
                 out = torch.empty_like(H0)
-                be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, False, H, H0, 1.0 - a, a, out)
+                be.spmm_dropped_chained(self.graph, scales[k], p, seed, first_stream + k, k > 0, nxt(k), H, H0, 1.0 - a, a, out)
                 H = out
             return H
         bufs = [torch.zeros((self.n_buf, C), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -755,7 +767,8 @@ class ShardedGraph:
         for k in range(iterations):
             src, dst = bufs[k % 2], bufs[1 - k % 2]
             self._pull(src, send)
-            be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, False, src, H0, 1.0 - a, a, self.local_view(dst))
+            be.spmm_dropped_chained(self.graph, scales[k], p, seed, first_stream + k, k > 0, nxt(k), src, H0, 1.0 - a, a,
+                                    self.local_view(dst))
         return self.local_view(bufs[iterations % 2]).clone()
 
     def propagate_dropped_backward(self, g, a, iterations, p, seed, first_stream, scales):

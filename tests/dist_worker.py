@@ -112,6 +112,19 @@ class OracleBackend:
             prod = prod + H0.numpy() * np.float32(alpha)
         out.copy_(torch.from_numpy(np.ascontiguousarray(prod, dtype=np.float32)))
 
+    def spmm_dropped_chained(self, g, D, p, seed, stream_id, prescaled, D_next, X, H0, beta, alpha, out):
+        rows, v = self._dropped_raw(g, p, seed, stream_id)
+        D = D.numpy()
+        w = D[rows + getattr(g, "row0_buf", 0)] * v
+        if not prescaled:
+            w = w * D[g.colidx]
+        m = sp.csr_matrix((w, g.colidx, g.rowptr), shape=g.shape)
+        res = (m @ X.numpy()) * np.float32(beta) + H0.numpy() * np.float32(alpha)
+        if D_next is not None:
+            r0 = getattr(g, "row0_buf", 0)
+            res = res * D_next.numpy()[r0:r0 + g.n_rows, None]
+        out.copy_(torch.from_numpy(np.ascontiguousarray(res, dtype=np.float32)))
+
     def spmm_t_mix(self, g, X, H0, beta, alpha, out):
         m = sp.csr_matrix((g.vals, g.colidx, g.rowptr), shape=g.shape)
         out.copy_(torch.from_numpy(np.ascontiguousarray((m.T @ X.numpy()) * np.float32(beta) + H0.numpy() * np.float32(alpha), dtype=np.float32)))
