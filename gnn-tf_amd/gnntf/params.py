@@ -1,7 +1,9 @@
 """Parameter registry of an architecture: WrappedVariable + VariableGenerator.
 
-Mirrors reference gnntf/core/nn/variables.py:4-66 with torch tensors in place of
-tf.Variable: same constructor arguments, same initialisation schemes, same sharing rule.
+Behavioural contract: reference gnntf/core/nn/variables.py:4-66 -- the constructor arguments of a variable, the initialisation
+schemes by name ('small' = U(+-1/sqrt(fan_out)) is the default, a float = U(+-that), 'zero', 'eye', 'ones', 'xavier', 'he',
+'bernouli'), ``create_var(..., shared_name=)`` handing out ONE tensor per shared name, ``vars()`` listing every variable in
+creation order and ``reset()`` re-drawing all of them.  The structure is this build's own: torch tensors, initialisers as a table.
 """
 from __future__ import annotations
 
@@ -24,79 +26,80 @@ def default_device() -> torch.device:
     return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
-def _uniform(shape, bound, device):
+def _symmetric_uniform(shape, bound, device):
     return (torch.rand(shape, device=device) * 2 - 1) * bound
 
 
+# name -> f(shape, device): the value a reset() draws (variables.py:17-36; xavier / he are Keras's GlorotUniform / HeUniform limits)
+_INITIALISERS = {
+    "zero": lambda shape, dev: torch.zeros(shape, device=dev),
+    "ones": lambda shape, dev: torch.ones(shape, device=dev),
+    "eye": lambda shape, dev: torch.eye(shape[1], device=dev),
+    "small": lambda shape, dev: _symmetric_uniform(shape, shape[1] ** -0.5, dev),
+    "xavier": lambda shape, dev: _symmetric_uniform(shape, math.sqrt(6.0 / (shape[0] + shape[1])), dev),
+    "he": lambda shape, dev: _symmetric_uniform(shape, math.sqrt(6.0 / shape[0]), dev),
+    "bernouli": lambda shape, dev: (torch.round(torch.rand(shape, device=dev)) * 2 - 1) * shape[1] ** -0.5,
+}
+
+
 class WrappedVariable(object):
-    """variables.py:4-45.  ``var`` is the raw tensor layers compute with."""
+    """One parameter: ``var`` is the raw tensor the layers compute with; ``regularize`` its weight-decay factor (a float, so that
+    ``regularize=False`` switches the decay off), ``normalization`` the initialiser it is reset with."""
 
     def __init__(self, shape, normalization='small', trainable=True, regularize=True, name=None):
+        self.name, self.normalization = name, normalization
+        self.trainable, self.regularize = trainable, float(regularize)
         self.var = torch.zeros(tuple(shape), dtype=torch.float32, device=default_device(), requires_grad=bool(trainable))
-        self.trainable = trainable
-        self.regularize = float(regularize)
-        self.name = name
-        self.normalization = normalization
-
-    def apply_gradient(self, optimizer, gradient):
-        if gradient is None:
-            return
-        self.var.grad = gradient
-        optimizer.step()
 
     def reset(self):
-        """Re-draws the value in place (variables.py:17-36)."""
-        shape, dev, kind = tuple(self.var.shape), self.var.device, self.normalization
-        if isinstance(kind, float):
-            value = _uniform(shape, kind, dev)
-        elif kind == 'zero':
-            value = torch.zeros(shape, device=dev)
-        elif kind == 'eye':
-            value = torch.eye(shape[1], device=dev)
-        elif kind == 'ones':
-            value = torch.ones(shape, device=dev)
-        elif kind == 'xavier':  # keras GlorotUniform: limit sqrt(6 / (fan_in + fan_out))
-            value = _uniform(shape, math.sqrt(6.0 / (shape[0] + shape[1])), dev)
-        elif kind == 'he':      # keras HeUniform: limit sqrt(6 / fan_in)
-            value = _uniform(shape, math.sqrt(6.0 / shape[0]), dev)
-        elif kind == 'bernouli':
-            value = (torch.round(torch.rand(shape, device=dev)) * 2 - 1) / shape[1] ** 0.5
-        elif kind == 'small':
-            value = _uniform(shape, 1. / (shape[1] ** 0.5), dev)
+        """Re-draws the value in place."""
+        scheme, shape, dev = self.normalization, tuple(self.var.shape), self.var.device
+        if isinstance(scheme, float):
+            fresh = _symmetric_uniform(shape, scheme, dev)
+        elif scheme in _INITIALISERS:
+            fresh = _INITIALISERS[scheme](shape, dev)
         else:
             raise Exception("Invalid normalization type")
-        self.assign(value)
-
-    def identity(self):
-        return self.var.detach().clone()
-
-    def numpy(self):
-        return self.var.detach().cpu().numpy()
+        self.assign(fresh)
 
     def assign(self, value):
         with torch.no_grad():
             self.var.copy_(torch.as_tensor(value, dtype=torch.float32, device=self.var.device).reshape(self.var.shape))
 
+    def identity(self):
+        """A detached copy (what the early-stopping snapshot keeps)."""
+        return self.var.detach().clone()
+
+    def numpy(self):
+        return self.identity().cpu().numpy()
+
+    def apply_gradient(self, optimizer, gradient):
+        if gradient is not None:
+            self.var.grad = gradient
+            optimizer.step()
+
 
 class VariableGenerator(object):
-    """variables.py:48-66."""
+    """Hands out parameters and remembers them: everything an architecture trains is created through ``create_var``."""
 
     def __init__(self):
-        self.__vars = list()
-        self.__named_vars = dict()
-
-    def vars(self):
-        return self.__vars
+        self._created = []          # every WrappedVariable, in creation order
+        self._by_shared_name = {}   # shared_name -> the raw tensor handed out under it
 
     def create_var(self, *args, shared_name=None, **kwargs):
-        if shared_name is not None and shared_name in self.__named_vars:
-            return self.__named_vars[shared_name]
-        var = WrappedVariable(*args, **kwargs)
-        self.__vars.append(var)
+        """The raw tensor of a new variable -- or, for a ``shared_name`` seen before, the tensor created under that name."""
+        known = self._by_shared_name.get(shared_name) if shared_name is not None else None
+        if known is not None:
+            return known
+        wrapped = WrappedVariable(*args, **kwargs)
+        self._created.append(wrapped)
         if shared_name is not None:
-            self.__named_vars[shared_name] = var.var
-        return var.var
+            self._by_shared_name[shared_name] = wrapped.var
+        return wrapped.var
+
+    def vars(self):
+        return self._created
 
     def reset(self):
-        for var in self.__vars:
-            var.reset()
+        for wrapped in self._created:
+            wrapped.reset()
