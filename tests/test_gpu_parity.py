@@ -85,6 +85,24 @@ def test_c_abi_argument_errors_on_device(gnntf):
     bad = c_void_p()
     rp = torch.tensor([0, 2, 1, 3], device="cuda"); ci = torch.tensor([0, 1, 2], dtype=torch.int32, device="cuda"); v = torch.ones(3, device="cuda")
     assert lib.gnx_graph_create_csr(3, 3, 3, nat.ptr(rp), nat.ptr(ci), nat.ptr(v), s, byref(bad)) == -1 and b"valid sorted CSR" in lib.gnx_last_error()
+    # round-2 entry points
+    from ctypes import c_float
+    D = torch.ones(50, device="cuda")
+    gid = torch.arange(30, dtype=torch.int32, device="cuda")
+    assert lib.gnx_graph_set_block(rect.handle, 0, 15, nat.ptr(gid), s) == -1 and b"do not fit" in lib.gnx_last_error()      # 20 rows behind column 15 of 30
+    assert lib.gnx_graph_set_block(rect.handle, 100, 5, nat.ptr(gid), s) == 0 and lib.gnx_graph_set_block(rect.handle, 0, 0, None, s) == 0
+    assert lib.gnx_spmm_dropped(rect.handle, nat.ptr(D), 0.5, 1, 1, 0, nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == -1
+    assert b"square graph or a vertex block" in lib.gnx_last_error()
+    dup = make_graph(gnntf, np.concatenate([coo, coo[:5]]), np.concatenate([vals, vals[:5]]), shape)
+    assert lib.gnx_spmm_dropped_chained(dup.handle, nat.ptr(D), 0.5, 1, 1, 0, None, nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16,
+                                        s) == -4 and b"duplicate" in lib.gnx_last_error()                                          # GNX_ERR_UNSUPPORTED
+    assert lib.gnx_spmm_dropped_chained(g.handle, None, 0.5, 1, 1, 0, None, nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == -1
+    ptrs, coefs = (c_void_p * 1)(X.data_ptr()), (c_float * 1)(1.0)
+    assert lib.gnx_linear_combination(0, ptrs, coefs, 16, nat.ptr(out), s) == -1 and b"1 to 16 terms" in lib.gnx_last_error()
+    assert lib.gnx_linear_combination(17, ptrs, coefs, 16, nat.ptr(out), s) == -1
+    assert lib.gnx_linear_combination(1, (c_void_p * 1)(X.data_ptr() + 4), coefs, 16, nat.ptr(out), s) == -1 and b"unaligned" in lib.gnx_last_error()
+    idx64 = torch.zeros(4, dtype=torch.int64, device="cuda")
+    assert lib.gnx_gather_rows(nat.ptr(X), 16, nat.ptr(idx64), 1 << 26, 16, nat.ptr(out), 16, s) == -1 and b"2^26" in lib.gnx_last_error()
     # the library still works after the failed calls
     assert call(nat.ptr(X), 16, 16, None, 0, 1.0, 0.0, 0, nat.ptr(out), 16, s) == 0
     want = orc.sparse_dense_matmul(coo, vals, shape, X.cpu().numpy())
