@@ -8,7 +8,7 @@
 
 #include "../../include/gnx.h"
 
-#define GNX_VERSION_NUM 200 /* 0.2.0 */
+#define GNX_VERSION_NUM 300 /* 0.3.0 */
 
 namespace gnx {
 

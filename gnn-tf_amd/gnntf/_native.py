@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
 NORM = {"none": 0, "symmetric": 1, "bipartite": 2}
 EYE = {"none": 0, "before": 1, "after": 2}
 ACT_NONE, ACT_RELU, ACT_SKIP_EMPTY = 0, 1, 256
+HALO_ALL, HALO_PULL, HALO_PUSH = 0, 1, 2
 
 # name -> (restype, argtypes); must list every symbol include/gnx.h declares
 SIGNATURES = {
@@ -52,11 +53,14 @@ SIGNATURES = {
     "gnx_ppr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
     "gnx_appnp_propagate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p]),
-    "gnx_halo_plan_create": (c_int, [c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
+    "gnx_halo_plan_create": (c_int, [c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "gnx_halo_plan_destroy": (c_int, [c_void_p]),
-    "gnx_halo_plan_layout": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p]),
-    "gnx_halo_pack": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
-    "gnx_halo_exchange": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gnx_halo_plan_layout": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p,
+                                     c_void_p]),
+    "gnx_halo_pack": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gnx_halo_exchange": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "gnx_halo_bind_rccl": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gnx_gather_rows32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gnx_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "gnx_gcnii_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p, c_int64, c_int, c_void_p,
                                c_void_p, c_void_p]),

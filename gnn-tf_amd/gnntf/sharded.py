@@ -96,6 +96,18 @@ class NativeBackend:
     def gather_rows(self, X, idx):
         return sparse.gather_rows(X, idx)
 
+    # ---- the exchange plan of a block: gnx_halo_plan_* (layout + packing of both halves of the send buffer) -------------
+    def halo_plan(self, rank, n_local, recv_pull, recv_push, send_pull, send_push, pull_src, push_graph):
+        return NativeHaloPlan(rank, n_local, recv_pull, recv_push, send_pull, send_push, pull_src, push_graph)
+
+    def halo_pack(self, plan, part, buf, send):
+        """The chosen half (or both) of the send buffer from the local rows of ``buf`` (gnx_halo_pack)."""
+        if plan.n_send == 0:
+            return
+        with nat.on_device(buf.device):
+            nat.check(nat.lib().gnx_halo_pack(plan.handle, PARTS[part], nat.ptr(buf), buf.stride(0), buf.shape[1], nat.ptr(send),
+                                              send.stride(0), nat.current_stream()))
+
     # ---- training with edge dropout on a vertex block (raw values; weights made inside the kernels) ----------
     def set_block(self, graph, row0_global, row0_buf, col_gid):
         """Dropout draws of this block are keyed by GLOBAL (row, col) from now on (gnx_graph_set_block)."""
@@ -133,6 +145,37 @@ class NativeBackend:
         if adj is None:
             adj = graph._plain_adjacency = sparse.Adjacency(graph, None)         # keeps the transposed-order values
         sparse._launch(adj, X, H0, beta, alpha, nat.ACT_NONE, transposed=True, out=out)
+
+
+PARTS = {"all": nat.HALO_ALL, "pull": nat.HALO_PULL, "push": nat.HALO_PUSH}
+
+
+class NativeHaloPlan:
+    """gnx_halo_plan_t of one vertex block: the library computes the layout of the feature and send buffers and packs the
+    outgoing rows; this object only keeps the handle and what it borrows alive."""
+
+    def __init__(self, rank, n_local, recv_pull, recv_push, send_pull, send_push, pull_src, push_graph):
+        from ctypes import byref, c_int64, c_void_p
+        P = len(recv_pull)
+        arr = lambda counts: (c_int64 * P)(*[int(c) for c in counts])
+        self._keep = (pull_src, push_graph)                       # borrowed by the plan
+        self.handle = c_void_p()
+        nat.check(nat.lib().gnx_halo_plan_create(P, int(rank), int(n_local), arr(recv_pull), arr(recv_push), arr(send_pull), arr(send_push),
+                                                 nat.ptr(pull_src) if pull_src is not None and pull_src.numel() else None,
+                                                 push_graph.handle if push_graph is not None else None, byref(self.handle)))
+        n_buf, local0, n_send, n_send_pull = c_int64(), c_int64(), c_int64(), c_int64()
+        recv0, pull0, push0 = (c_int64 * P)(), (c_int64 * P)(), (c_int64 * P)()
+        nat.check(nat.lib().gnx_halo_plan_layout(self.handle, byref(n_buf), byref(local0), byref(n_send), byref(n_send_pull), recv0, pull0, push0))
+        self.n_buf, self.local_row0, self.n_send, self.n_send_pull = n_buf.value, local0.value, n_send.value, n_send_pull.value
+        self.recv_row0, self.send_pull_row0, self.send_push_row0 = list(recv0), list(pull0), list(push0)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                nat.lib().gnx_halo_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class Comm:
@@ -186,25 +229,26 @@ class Comm:
         return [x.to(t.device) for x in table]
 
     def exchange(self, send_chunks, recv_chunks):
-        """Pairwise exchange: send_chunks[q] goes to group rank q, recv_chunks[q] is filled from it.
-        One batch of point-to-point operations (NCCL/RCCL: a single group call, every peer pair on
-        its own xGMI link).  Stream-ordered on the current stream for RCCL groups."""
+        """Pairwise exchange: send_chunks[q] goes to group rank q, recv_chunks[q] is filled from it (None / empty: nothing)."""
+        self.exchange_pairs([(q, t) for q, t in enumerate(send_chunks) if q != self.rank],
+                            [(q, t) for q, t in enumerate(recv_chunks) if q != self.rank])
+
+    def exchange_pairs(self, sends, recvs):
+        """``sends`` / ``recvs``: lists of (group rank, tensor); several messages per peer are matched in list order.
+        One batch of point-to-point operations (NCCL/RCCL: a single group call, every peer pair on its own xGMI link).
+        Stream-ordered on the current stream for RCCL groups."""
         if self.size == 1:
             return
-        if any(self._staged(t) for t in list(send_chunks) + list(recv_chunks)):
-            host_recv = [None if t is None else torch.empty(t.shape, dtype=t.dtype) for t in recv_chunks]
-            self.exchange([None if t is None else t.cpu() for t in send_chunks], host_recv)
-            for q, (d, h) in enumerate(zip(recv_chunks, host_recv)):
-                if q != self.rank and d is not None and d.numel() > 0:
-                    d.copy_(h)
+        sends = [(q, t) for q, t in sends if t is not None and t.numel() > 0]
+        recvs = [(q, t) for q, t in recvs if t is not None and t.numel() > 0]
+        if any(self._staged(t) for _, t in sends + recvs):
+            host_recv = [(q, torch.empty(t.shape, dtype=t.dtype)) for q, t in recvs]
+            self.exchange_pairs([(q, t.cpu()) for q, t in sends], host_recv)
+            for (_, d), (_, h) in zip(recvs, host_recv):
+                d.copy_(h)
             return
-        ops = []
-        for q, t in enumerate(recv_chunks):
-            if q != self.rank and t is not None and t.numel() > 0:
-                ops.append(dist.P2POp(dist.irecv, t, self._global(q), self.group))
-        for q, t in enumerate(send_chunks):
-            if q != self.rank and t is not None and t.numel() > 0:
-                ops.append(dist.P2POp(dist.isend, t, self._global(q), self.group))
+        ops = [dist.P2POp(dist.irecv, t, self._global(q), self.group) for q, t in recvs]
+        ops += [dist.P2POp(dist.isend, t, self._global(q), self.group) for q, t in sends]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
@@ -379,7 +423,7 @@ class ShardedGraph:
     MIN_INTERIOR_SHARE = 0.05      # share of a block's entries that must sit in interior rows for the interior / boundary split to pay
 
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
-                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False):
+                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False, early_pull=False):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
         (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.  Collective: every rank of the
         vertex partition (``comm`` / ``group``) must call it with the same options.
@@ -390,6 +434,7 @@ class ShardedGraph:
         ``self.entries`` (tests).  ``relabel`` (single vertex block only): store the shard with its vertices relabelled in stable order of
         descending entry count -- a legal preprocessing step that makes the sub-wave kernels
         5-20 % faster; propagate() permutes H0 on the way in and the result on the way out.
+        ``early_pull``: propagate() sends the pulled rows ahead of the pushed partial sums (see propagate).
         ``edge_dropout``: build the block for TRAINING with per-iteration edge dropout (layered.py:47-50 + gnn.py:41-42):
         raw values (``normalized`` is ignored -- every iteration re-normalises its own dropped entries), classic halo, whole
         rows; use dropped_scales / propagate_dropped / propagate_dropped_backward instead of propagate()."""
@@ -413,7 +458,8 @@ class ShardedGraph:
         lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         N = self.bounds[-1]
         self.lo, self.hi, self.n_global, self.n_local = lo, hi, N, hi - lo
-        self.cover, self.chunks = cover, max(1, int(chunks))
+        self.cover, self.chunks, self.early_pull = cover, max(1, int(chunks)), bool(early_pull)
+        self.n_send_pull_max = self.n_send_push_max = 0
         if idx_global.numel() and (int(idx_global[:, 0].min()) < lo or int(idx_global[:, 0].max()) >= hi):
             raise Exception("ShardedGraph: an entry's row is outside this rank's range [%d, %d)" % (lo, hi))
 
@@ -470,7 +516,8 @@ class ShardedGraph:
         self.n_buf, self.n_before = self.n_local, 0
         self.recv_counts, self.send_counts = [0], [0]
         self.pull_counts, self.push_counts = [0], [0]
-        self.n_send = 0
+        self.n_send = self.n_send_pull = 0
+        self.send_graph = self.push_graph = self.halo = None
         self.stats = dict(pull_rows=0, push_rows=0, pull_only_rows=0, send_rows=0, interior_rows=self.n_local,
                           boundary_rows=0, local_rows=self.n_local)
 
@@ -538,31 +585,57 @@ class ShardedGraph:
         self.pull_counts = [int(c) for c in pull_counts.tolist()]
         self.push_counts = [int(c) for c in push_counts.tolist()]
         self.recv_counts = [a + b for a, b in zip(self.pull_counts, self.push_counts)]
-        rs = region_start.tolist()
-        self.recv_slices = [(int(rs[q]), int(rs[q]) + self.recv_counts[q]) for q in range(P)]
-        s_rows, s_cols, s_vals, self.send_counts, self.send_slices = [], [], [], [], []
-        base = 0
+        rs = [int(x) for x in region_start.tolist()]
+        self.recv_slices = [(rs[q], rs[q] + self.recv_counts[q]) for q in range(P)]
+        self.recv_pull_slices = [(rs[q], rs[q] + self.pull_counts[q]) for q in range(P)]
+        self.recv_push_slices = [(rs[q] + self.pull_counts[q], rs[q] + self.recv_counts[q]) for q in range(P)]
+        # the send buffer: [rows the peers pull, peer by peer | partial sums pushed to the peers, peer by peer].  The first half is
+        # a gather of local rows, the second the product of the push graph with the local rows (gnx_halo_pack).
+        self.send_pull_counts = [0 if g == me else int(asked_ids[g].numel()) for g in range(P)]
+        self.send_push_counts = [0 if g == me else int(table[g][me]) for g in range(P)]
+        self.send_counts = [a + b for a, b in zip(self.send_pull_counts, self.send_push_counts)]
+        self.n_send_pull, n_push = sum(self.send_pull_counts), sum(self.send_push_counts)
+        self.n_send = self.n_send_pull + n_push
+        self.send_pull_slices, self.send_push_slices = [], []
+        at_pull, at_push = 0, self.n_send_pull
+        s_rows, s_cols, s_vals = [], [], []
         for g in range(P):
-            a_g = 0 if g == me else int(asked_ids[g].numel())
-            b_g = 0 if g == me else int(table[g][me])
+            a_g, b_g = self.send_pull_counts[g], self.send_push_counts[g]
             if g != me:
                 e = edges[g].reshape(-1, 2)
                 if b_g == 0 and e.shape[0] != 0 or (e.shape[0] and int(e[:, 0].max()) >= b_g):
                     raise Exception("ShardedGraph: a peer's push plan is inconsistent")
-                s_rows += [base + torch.arange(a_g, device=dev), base + a_g + e[:, 0]]
-                s_cols += [asked_ids[g] - lo, e[:, 1] - lo]
-                s_vals += [torch.ones(a_g, dtype=torch.float32, device=dev), evals[g]]
-            self.send_counts.append(a_g + b_g)
-            self.send_slices.append((base, base + a_g + b_g))
-            base += a_g + b_g
-        self.n_send = base
+                s_rows.append(at_push - self.n_send_pull + e[:, 0])
+                s_cols.append(e[:, 1] - lo)
+                s_vals.append(evals[g])
+            self.send_pull_slices.append((at_pull, at_pull + a_g))
+            self.send_push_slices.append((at_push, at_push + b_g))
+            at_pull, at_push = at_pull + a_g, at_push + b_g
+        pull_src = torch.cat([asked_ids[g] - lo for g in range(P) if g != me]) if P > 1 else torch.zeros(0, dtype=torch.int64, device=dev)
+        if pull_src.numel() and (int(pull_src.min()) < 0 or int(pull_src.max()) >= n_local):
+            raise Exception("ShardedGraph: a peer asked for a row this rank does not own")
+        self.send_pull_src = pull_src.to(torch.int32)
         s_rows = torch.cat(s_rows) if s_rows else torch.zeros(0, dtype=torch.int64, device=dev)
         s_cols = torch.cat(s_cols) if s_cols else torch.zeros(0, dtype=torch.int64, device=dev)
         s_vals = torch.cat(s_vals) if s_vals else torch.zeros(0, dtype=torch.float32, device=dev)
         if s_cols.numel() and (int(s_cols.min()) < 0 or int(s_cols.max()) >= n_local):
-            raise Exception("ShardedGraph: a peer asked for a row this rank does not own")
-        self.send_graph = be.graph_from_coo(torch.stack([s_rows, s_cols], 1), s_vals, (self.n_send, n_local)) if self.n_send else None
-        del s_rows, s_cols, s_vals, asked_ids, edges, evals
+            raise Exception("ShardedGraph: a peer asked for a partial sum over rows this rank does not own")
+        self.push_graph = be.graph_from_coo(torch.stack([s_rows, s_cols], 1), s_vals, (n_push, n_local)) if n_push else None
+        self.halo = be.halo_plan(me, n_local, self.pull_counts, self.push_counts, self.send_pull_counts, self.send_push_counts,
+                                 self.send_pull_src, self.push_graph)
+        # the library's layout of the two buffers is THE layout: what this module computed above must agree with it
+        if (self.halo.n_buf, self.halo.local_row0, self.halo.n_send, self.halo.n_send_pull) != (self.n_buf, n_before, self.n_send, self.n_send_pull) \
+                or any(self.halo.recv_row0[q] != rs[q] for q in range(P) if self.recv_counts[q]) \
+                or any(self.halo.send_pull_row0[q] != self.send_pull_slices[q][0] for q in range(P) if self.send_pull_counts[q]) \
+                or any(self.halo.send_push_row0[q] != self.send_push_slices[q][0] for q in range(P) if self.send_push_counts[q]):
+            raise Exception("ShardedGraph: the halo plan's layout disagrees with the block's")
+        # training with edge dropout sends what this rank computed for its halo columns BACK to their owners, who add it up
+        # through the transposed send graph (a pulled row = one entry of weight 1); only that mode needs it as a graph
+        self.send_graph = None
+        if self.edge_dropout and self.n_send_pull:
+            self.send_graph = be.graph_from_coo(torch.stack([torch.arange(self.n_send_pull, device=dev), pull_src], 1),
+                                                torch.ones(self.n_send_pull, dtype=torch.float32, device=dev), (self.n_send_pull, n_local))
+        del s_rows, s_cols, s_vals, asked_ids, edges, evals, pull_src
 
         # ---- the main CSR over X; interior rows (no remote column: their sums need no halo) apart -------------
         n_bnd = int(is_bnd.sum())
@@ -590,6 +663,9 @@ class ShardedGraph:
             be.set_block(self.graph, lo, n_before, gid)
         self.stats = dict(pull_rows=sum(self.pull_counts), push_rows=sum(self.push_counts), pull_only_rows=n_pull_only,
                           send_rows=self.n_send, interior_rows=n_local - n_bnd, boundary_rows=n_bnd, local_rows=n_local)
+        t = torch.tensor([self.n_send_pull, self.n_send - self.n_send_pull], dtype=torch.int64, device=dev)
+        comm.all_reduce(t, dist.ReduceOp.MAX)
+        self.n_send_pull_max, self.n_send_push_max = int(t[0]), int(t[1])
 
     # ---- propagation -----------------------------------------------------------------------------
     def local_view(self, buf):
@@ -614,15 +690,27 @@ class ShardedGraph:
         state.result = torch.empty_like(H0)
         return state
 
-    def _pack(self, state, c, buf):
-        """Every outgoing row of chunk c (pulled rows and pushed partial sums) from the local part of ``buf``."""
-        if self.send_graph is not None:
-            self.backend.spmm_plain(self.send_graph, self.local_view(buf), state.send[c][:self.n_send])
+    def _pack(self, state, c, buf, part="all"):
+        """Outgoing rows of chunk c from the local part of ``buf``: the rows the peers pull ("pull": a gather), the partial sums
+        pushed to them ("push": an SpMM over the entries this rank sums for its peers), or both."""
+        if self.n_send:
+            self.backend.halo_pack(self.halo, part, buf, state.send[c])
 
-    def _exchange(self, state, c, buf):
-        sends = [state.send[c][a:b] if b > a else None for a, b in self.send_slices]
-        recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
-        self.comm.exchange(sends, recvs)
+    def _exchange(self, state, c, buf, part="all"):
+        """One group of point-to-point transfers: the chosen half (or both halves) of every peer's message."""
+        sends, recvs = [], []
+        for q in range(self.world):
+            if part != "push":
+                a, b = self.send_pull_slices[q]
+                sends.append((q, state.send[c][a:b]))
+                a, b = self.recv_pull_slices[q]
+                recvs.append((q, buf[a:b]))
+            if part != "pull":
+                a, b = self.send_push_slices[q]
+                sends.append((q, state.send[c][a:b]))
+                a, b = self.recv_push_slices[q]
+                recvs.append((q, buf[a:b]))
+        self.comm.exchange_pairs(sends, recvs)
 
     def _compute(self, state, c, src, out, a, interior, skip_empty=False):
         c0, c1 = state.cols[c]
@@ -635,10 +723,11 @@ class ShardedGraph:
         else:
             self.backend.spmm_mix(self.graph, None, src, H0, 1.0 - a, a, out, rows=self.rows_bnd, skip_empty=skip_empty)
 
-    def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10, start=None):
+    def propagate(self, state: ShardState, a: float = 0.1, iterations: int = 10, start=None, early_pull=None):
         """H <- H0 (or ``start``: this rank's rows of another initial H, e.g. the input of a GCNII layer whose mix term is
         H0), then K iterations of H <- (1-a) A_hat H + a H0; returns this rank's rows of the result (in the caller's vertex
-        order)."""
+        order).  ``early_pull`` (default: the graph's setting): the rows the peers pull go on the links as soon as they are
+        gathered, while the pushed partial sums are still being summed -- two messages per peer and iteration instead of one."""
         if start is not None and tuple(start.shape) != tuple(state.H0_user.shape if self.row_order is not None else state.H0.shape):
             raise Exception("propagate: start must have the shape of H0")
         if self.world == 1:
@@ -647,12 +736,20 @@ class ShardedGraph:
         if iterations == 0:
             state.result.copy_(first)
             return state.result
+        early = self.early_pull if early_pull is None else bool(early_pull)
+        early = early and self.n_send_pull_max > 0 and self.n_send_push_max > 0       # (collective decision: every rank takes the same branch)
         lanes = self._lanes
         packed = []
+
+        def pack(c, buf):
+            self._pack(state, c, buf, "pull")
+            half = lanes.mark() if early else None
+            self._pack(state, c, buf, "push")
+            return half, lanes.mark()
+
         for c, (c0, c1) in enumerate(state.cols):
             self.local_view(state.bufs[c][0]).copy_(first[:, c0:c1])
-            self._pack(state, c, state.bufs[c][0])
-            packed.append(lanes.mark())
+            packed.append(pack(c, state.bufs[c][0]))
         for k in range(iterations):
             last = k == iterations - 1
             # a row without entries is a * H0 after every iteration: it is written the first time each ping-pong buffer is a
@@ -661,16 +758,22 @@ class ShardedGraph:
             for c, (c0, c1) in enumerate(state.cols):
                 src, dst = state.bufs[c][k % 2], state.bufs[c][1 - k % 2]
                 with lanes.exchange_lane():                            # runs under the other chunk's SpMM
-                    lanes.wait(packed[c], on_exchange_lane=True)
-                    self._exchange(state, c, src)
+                    half, whole = packed[c]
+                    if early:
+                        lanes.wait(half, on_exchange_lane=True)
+                        self._exchange(state, c, src, "pull")
+                        lanes.wait(whole, on_exchange_lane=True)
+                        self._exchange(state, c, src, "push")
+                    else:
+                        lanes.wait(whole, on_exchange_lane=True)
+                        self._exchange(state, c, src, "all")
                     arrived = lanes.mark(on_exchange_lane=True)
                 out = state.result[:, c0:c1] if last else self.local_view(dst)
                 self._compute(state, c, src, out, a, interior=True, skip_empty=settled)    # needs no halo
                 lanes.wait(arrived)
                 self._compute(state, c, src, out, a, interior=False, skip_empty=settled)
                 if not last:
-                    self._pack(state, c, dst)
-                    packed[c] = lanes.mark()
+                    packed[c] = pack(c, dst)
         return state.result
 
     def _propagate_single_block(self, state, a, iterations, start=None):
@@ -705,18 +808,16 @@ class ShardedGraph:
 
     def _exchange_back(self, full, back):
         """The regions of ``full`` go back to their owners; ``back`` [n_send, C] receives what the peers hold for the rows this
-        rank sends them."""
-        sends = [full[a:b] if b > a else None for a, b in self.recv_slices]
-        recvs = [back[a:b] if b > a else None for a, b in self.send_slices]
-        self.comm.exchange(sends, recvs)
+        rank sends them (an edge-dropout block pulls only: every message is one slice)."""
+        self.comm.exchange([full[a:b] if b > a else None for a, b in self.recv_slices],
+                           [back[a:b] if b > a else None for a, b in self.send_pull_slices])
 
     def _pull(self, buf, send):
-        """Fills the regions of ``buf`` from the peers' local rows (one pack launch + one pairwise exchange)."""
-        if self.send_graph is not None:
-            self.backend.spmm_plain(self.send_graph, self.local_view(buf), send[:self.n_send])
-        sends = [send[a:b] if b > a else None for a, b in self.send_slices]
-        recvs = [buf[a:b] if b > a else None for a, b in self.recv_slices]
-        self.comm.exchange(sends, recvs)
+        """Fills the regions of ``buf`` from the peers' local rows (one gather launch + one pairwise exchange)."""
+        if self.n_send:
+            self.backend.halo_pack(self.halo, "pull", buf, send)
+        self.comm.exchange([send[a:b] if b > a else None for a, b in self.send_pull_slices],
+                           [buf[a:b] if b > a else None for a, b in self.recv_slices])
 
     def _add_back(self, full, back, out):
         """out = the local rows of ``full`` + what the peers computed for them (``back``, summed by the transposed send graph:
@@ -871,10 +972,20 @@ class ShardedGraph:
         self.comm.all_reduce(t, dist.ReduceOp.MAX)
         out["max_halo_rows"] = int(t.item())
         out["cover"], out["split_rows"], out["chunks"] = self.cover, bool(getattr(self, "split_rows", False)), self.chunks
+        out["early_pull"] = self.early_pull
         return out
 
 
-# ---- the other parts of the vertex-block path, under their historical names -------------------------------------------------
-from .sharded_layers import (BlockNodeClassification, ShardedGCNIILayer, ShardedGCNLayer, ShardedPPRLoop,  # noqa: E402,F401
-                             SummedGradients)
-from .rmat import build_rmat_blocks, build_rmat_shard, rmat_relabelled_pairs, rmat_undirected_keys  # noqa: E402,F401
+# ---- the other parts of the vertex-block path, under their historical names ------------------------------------------------
+# Resolved on first use (PEP 562): rmat.py and sharded_layers.py import THIS module, so importing them here at load time would
+# make `import gnntf.rmat` fail on a half-initialised gnntf.sharded.
+_MOVED = {name: "sharded_layers" for name in ("BlockNodeClassification", "ShardedGCNIILayer", "ShardedGCNLayer", "ShardedPPRLoop",
+                                              "SummedGradients")}
+_MOVED.update({name: "rmat" for name in ("build_rmat_blocks", "build_rmat_shard", "rmat_relabelled_pairs", "rmat_undirected_keys")})
+
+
+def __getattr__(name):
+    if name in _MOVED:
+        import importlib
+        return getattr(importlib.import_module("." + _MOVED[name], __package__), name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

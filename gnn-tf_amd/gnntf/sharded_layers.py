@@ -224,11 +224,14 @@ class ShardedGCNIILayer(Layer):
 class SummedGradients:
     """Optimizer wrapper for models that hold one vertex block each: before every step the gradients of the (replicated)
     parameters are summed over the ranks, so every rank applies the same update -- what one process holding all rows would
-    compute, given a task that scales its local loss by the GLOBAL item count (BlockNodeClassification).
+    compute, given a task that scales its local loss by the GLOBAL item count (BlockNodeClassification).  Terms of the objective
+    that do not depend on the rows -- the weight decay -- are held by every rank alike: train() reads ``replicas`` and lets each
+    rank contribute 1/replicas of them, so the default ``regularization`` gives the one-process update.
     Use as ``architecture.train(..., optimizer=lambda params: SummedGradients(torch.optim.Adam(params, ...), comm))``."""
 
     def __init__(self, optimizer, comm):
         self.optimizer, self.comm = optimizer, comm
+        self.replicas = comm.size
 
     def zero_grad(self, set_to_none=True):
         self.optimizer.zero_grad(set_to_none=set_to_none)

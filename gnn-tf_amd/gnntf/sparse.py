@@ -155,7 +155,12 @@ class DroppedAdjacency(Adjacency):
     """The dropped + symmetrically re-normalised adjacency of one training iteration (layered.py:47-50 + gnn.py:41-42) WITHOUT
     its nnz-sized value array: only the N degree scales are computed up front; the SpMM kernels produce every entry's weight
     (D[row] * dropout(raw)) * D[col] from the counter RNG while they gather (gnx_spmm_dropped) -- forward and transposed, bit
-    for bit the values gnx_graph_normalize would have written.  ``.vals`` materialises them on demand (custom layers)."""
+    for bit the values gnx_graph_normalize would have written.  ``.vals`` materialises them on demand (custom layers).
+    PRECONDITION: finite features and finite degree scales.  A dropped entry is SKIPPED here (its row is not gathered), whereas
+    the reference keeps it as an explicit zero (tf.nn.dropout on G.values, layered.py:50), so 0 * inf or 0 * NaN in the
+    gathered row -- or a NaN scale from a negative column sum -- makes a NaN there and not here.  For exact NaN propagation
+    use the materialised form (``normalize(graph, "symmetric", "none", p, seed, stream)`` + ``spmm``), which multiplies every
+    stored entry."""
 
     def __init__(self, graph: DeviceGraph, p, seed, stream_id, D=None):
         super().__init__(graph, None, None, None)
@@ -441,7 +446,9 @@ def linear_combination(terms) -> torch.Tensor:
     (gnx_linear_combination; terms are added in list order).  Returns a new tensor."""
     if not 1 <= len(terms) <= LINCOMB_TERMS:
         raise Exception("linear_combination: 1 to %d terms" % LINCOMB_TERMS)
-    tensors = [t if t.is_contiguous() else t.contiguous() for t, _ in terms]
+    # the kernel reads 16 bytes per lane: a contiguous VIEW with a storage offset (a row or column slice of a padded buffer)
+    # need not be 16-byte aligned -- such a term is copied to a fresh allocation first
+    tensors = [t if t.is_contiguous() and t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format) for t, _ in terms]
     first = tensors[0]
     nat.require_cuda(*tensors)
     for t in tensors:

@@ -41,10 +41,14 @@ class _Objective:
     forward, plus ``layer.loss()`` of every layer with an output penalty, plus
     ``regularization * var.regularize * sum(var^2)/2`` (= tf.nn.l2_loss) of every regularised variable."""
 
-    def __init__(self, model: "Trainable", task: Predictor, weight_decay: float):
+    def __init__(self, model: "Trainable", task: Predictor, weight_decay: float, replicas: int = 1):
+        """``replicas``: how many processes hold a copy of the variables and ADD their gradients up before each step (models over
+        vertex blocks, sharded_layers.SummedGradients).  The task loss and the output penalties are sums over rows, of which every
+        process holds its own; the weight decay is a property of the variables, which all of them hold -- each contributes 1/replicas
+        of it, so that ``regularization`` means the same thing for one process and for P."""
         self.model, self.task = model, task
         self.penalised_layers = [layer for layer in model.layers() if layer.output_regularize != 0]
-        self.decayed = [(weight_decay * v.regularize, v.var) for v in model.vars() if v.regularize != 0]
+        self.decayed = [(weight_decay * v.regularize / max(int(replicas), 1), v.var) for v in model.vars() if v.regularize != 0]
 
     def __call__(self):
         total = self.task.loss(self.model(self.model.features))
@@ -177,7 +181,7 @@ class Trainable(Layered):
                                         batches, optimizer)
         optimizer = self._make_optimizer(optimizer, learning_rate)
         judge = train if valid is None else valid
-        objective = _Objective(self, train, regularization)
+        objective = _Objective(self, train, regularization, replicas=getattr(optimizer, "replicas", 1))
         best = _BestSoFar(self.vars(), patience)
         for epoch in range(epochs):
             self._fast_predict = None

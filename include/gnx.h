@@ -177,7 +177,9 @@ int gnx_spmm_scatter(gnx_graph_t g, const float *d_vals, const float *d_diag, co
  * gnx_graph_normalize(g, GNX_NORM_SYMMETRIC, GNX_EYE_NONE, dropout_p, seed, stream_id, ...) followed by gnx_spmm.
  * d_D [n]: the degree scales of that iteration = gnx_graph_colsum(g, dropout_p, seed, stream_id, d_D) then
  * gnx_degree_scale(d_D, n, GNX_NORM_SYMMETRIC, 0).  Saves the nnz-sized value array and the pass that writes it
- * (layered.py:47-50 + gnn.py:41-42 happen in the SpMM's value fetch).  Square graphs or vertex blocks (gnx_graph_set_block);
+ * (layered.py:47-50 + gnn.py:41-42 happen in the SpMM's value fetch).  PRECONDITION: finite d_X and d_D -- a dropped entry is
+ * skipped (its row of d_X is not read), while the two-call form multiplies it by an explicit zero, so a non-finite row behind a
+ * dropped entry, or a NaN scale, turns the two-call result into NaN and not this one.  Square graphs or vertex blocks (gnx_graph_set_block);
  * GNX_ERR_UNSUPPORTED when the COO held
  * duplicate entries (their per-entry dropout needs the entry lists: use gnx_graph_normalize). */
 int gnx_spmm_dropped(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int transposed,
@@ -264,26 +266,41 @@ int gnx_node_argmax(const float *d_logits, int64_t ldl, int64_t n_rows, int64_t 
 /* ---- vertex-partitioned propagation (multi-GPU; the reference has no counterpart -- SURVEY.md section 8(e)) ----------------
  * One process per GPU owns a contiguous block of rows.  Its feature buffer is
  *     X = [ region(0) .. region(self-1) | n_local local rows | region(self+1) .. region(n_ranks-1) ],
- * region(q) = the recv_rows[q] rows rank q sends per iteration: rows of H pulled from q and/or partial sums
- * sum_j A_hat[i, j] H[j] pushed by q for rows i of this block (the caller's plan decides which; gnntf/sharded.py chooses a
- * vertex cover of the cross entries).  The main CSR of the block indexes X directly (gnx_graph_create_coo / _csr over
- * n_buf columns; pushed partial sums appear as weight-1 entries); the SEND graph [sum(send_rows) x n_local] produces every
- * outgoing row as a sparse combination of local rows (a pulled row = one entry of weight 1), in peer order.
- *   gnx_halo_plan_create   counts per peer (rows; [self] must be 0) + the send graph (borrowed; may be NULL when nothing is sent)
- *   gnx_halo_plan_layout   n_buf, first local row, rows to send, first row of every peer's region in X / in the send buffer
- *   gnx_halo_pack          d_send[n_send, C] = send_graph . X[local rows]          (one SpMM launch; stream-ordered)
- *   gnx_halo_exchange      RCCL group of ncclRecv into the regions of d_X + ncclSend of the slices of d_send; d_X and d_send
- *                          contiguous with row length C; `nccl_comm` is the caller's ncclComm_t whose ranks are the plan's
- *                          ranks.  Returns GNX_ERR_UNSUPPORTED when RCCL's symbols are not loaded in the process: move the
- *                          rows yourself (any transport) using the offsets of gnx_halo_plan_layout.
+ * region(q) = [ rows of H PULLED from rank q | partial sums sum_j A_hat[i, j] H[j] PUSHED by q for rows i of this block ]
+ * (the caller's plan decides which entries are pulled and which pushed; gnntf/sharded.py chooses a vertex cover of the cross
+ * entries).  The main CSR of the block indexes X directly (gnx_graph_create_coo / _csr over n_buf columns; pushed partial sums
+ * appear as weight-1 entries).  The SEND buffer is [ pulled rows for peer 0, 1, .. | pushed rows for peer 0, 1, .. ]:
+ * the pulled half is a gather of local rows (d_send_pull_src: the LOCAL row of every pulled row, int32, in send order), the
+ * pushed half the product of the PUSH graph [sum(send_push_rows) x n_local] with the local rows.  The two halves can be packed
+ * and exchanged separately (GNX_HALO_PULL, GNX_HALO_PUSH): the pulled rows cost a short copy and can be on the links while the
+ * partial sums -- most of the pack time -- are still being summed; GNX_HALO_ALL does both in one call / one RCCL group.
+ *   gnx_halo_plan_create   per-peer row counts of both halves in both directions + the pulled-row list + the push graph (both
+ *                          borrowed; NULL when the half is empty).  A rank may list itself as a peer (loop-back region after the
+ *                          local rows): a one-rank communicator then carries a real send / receive pair (tests on one GPU)
+ *   gnx_halo_plan_layout   n_buf, first local row, rows to send (total, pulled half), first row of every peer's region in X,
+ *                          first row of every peer's slice of the pulled / of the pushed half of the send buffer (any NULL = skip)
+ *   gnx_halo_pack          d_send (row length lds) <- the chosen half (or both) from the local rows of d_X; stream-ordered
+ *   gnx_halo_exchange      one RCCL group: ncclRecv into the chosen half of every region of d_X + ncclSend of the matching slices
+ *                          of d_send; d_X and d_send contiguous with row length C; `nccl_comm` is the caller's ncclComm_t whose
+ *                          ranks are the plan's ranks.  GNX_ERR_UNSUPPORTED when no RCCL entry points are known: move the rows
+ *                          yourself (any transport) using the offsets of gnx_halo_plan_layout
+ *   gnx_halo_bind_rccl     hands over ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv of the library instance that created
+ *                          the communicator (all NULL = unbind).  Without it the exchange looks the symbols up in the RCCL that
+ *                          is ALREADY loaded in the process; it never loads a copy of its own
  * One iteration = gnx_halo_pack -> exchange -> gnx_spmm (or gnx_spmm_rows) over X into the local rows of the other buffer. */
-int gnx_halo_plan_create(int n_ranks, int self, int64_t n_local, const int64_t *recv_rows, const int64_t *send_rows,
-                         gnx_graph_t send_graph, gnx_halo_plan_t *out);
+enum { GNX_HALO_ALL = 0, GNX_HALO_PULL = 1, GNX_HALO_PUSH = 2 };
+int gnx_halo_plan_create(int n_ranks, int self, int64_t n_local, const int64_t *recv_pull_rows, const int64_t *recv_push_rows,
+                         const int64_t *send_pull_rows, const int64_t *send_push_rows, const int32_t *d_send_pull_src,
+                         gnx_graph_t push_graph, gnx_halo_plan_t *out);
 int gnx_halo_plan_destroy(gnx_halo_plan_t plan);
-int gnx_halo_plan_layout(gnx_halo_plan_t plan, int64_t *n_buf, int64_t *local_row0, int64_t *n_send, int64_t *recv_row0,
-                         int64_t *send_row0);
-int gnx_halo_pack(gnx_halo_plan_t plan, const float *d_X, int64_t ldx, int64_t C, float *d_send, int64_t lds, void *stream);
-int gnx_halo_exchange(gnx_halo_plan_t plan, void *nccl_comm, const float *d_send, float *d_X, int64_t C, void *stream);
+int gnx_halo_plan_layout(gnx_halo_plan_t plan, int64_t *n_buf, int64_t *local_row0, int64_t *n_send, int64_t *n_send_pull,
+                         int64_t *recv_row0, int64_t *send_pull_row0, int64_t *send_push_row0);
+int gnx_halo_pack(gnx_halo_plan_t plan, int part, const float *d_X, int64_t ldx, int64_t C, float *d_send, int64_t lds, void *stream);
+int gnx_halo_exchange(gnx_halo_plan_t plan, int part, void *nccl_comm, const float *d_send, float *d_X, int64_t C, void *stream);
+int gnx_halo_bind_rccl(void *nccl_group_start, void *nccl_group_end, void *nccl_send, void *nccl_recv);
+/* out[r,:] = X[idx[r],:] for int32 row ids (the pulled half of gnx_halo_pack as a call of its own); any width, grid-stride. */
+int gnx_gather_rows32(const float *d_X, int64_t ldx, const int32_t *d_idx, int64_t n_idx, int64_t C, float *d_out, int64_t ldo,
+                      void *stream);
 
 /* The link head, LinkPrediction.predict / loss (gnntf/core/gnn/graph_predictor.py:122-126, 136-144): the logit of every listed
  * edge, d_out[i] = sum_c F[u_i, c] * F[v_i, c] * (d_r[c] or 1) -- gather of both endpoint rows + product + (DistMult) weights

@@ -43,34 +43,40 @@ static int two_block_plan(void) {
     /* block 0: X0 = [v0, v1 | slot pushed by block 1];  block 1: X1 = [v1 pulled from block 0 | v2, v3] */
     const int64_t m0_idx[6] = {0, 1, 1, 0, 1, 2};   const float m0_val[3] = {w01, w01, 1.f};
     const int64_t m1_idx[6] = {0, 0, 0, 2, 1, 1};   const float m1_val[3] = {w12, w23, w23};
-    const int64_t s0_idx[2] = {0, 1};               const float s0_val[1] = {1.f};     /* to block 1: the row H[1] */
-    const int64_t s1_idx[2] = {0, 0};               const float s1_val[1] = {w12};     /* to block 0: w12 * H[2] */
-    void *d_m0i, *d_m0v, *d_m1i, *d_m1v, *d_s0i, *d_s0v, *d_s1i, *d_s1v;
+    const int32_t pull0_src[1] = {1};                                                   /* block 0 -> 1: its local row 1 (= H[1]), a copy */
+    const int64_t push1_idx[2] = {0, 0};            const float push1_val[1] = {w12};   /* block 1 -> 0: w12 * H[2], summed by the sender */
+    void *d_m0i, *d_m0v, *d_m1i, *d_m1v, *d_p0s, *d_p1i, *d_p1v;
     if (upload(m0_idx, sizeof m0_idx, &d_m0i) || upload(m0_val, sizeof m0_val, &d_m0v) || upload(m1_idx, sizeof m1_idx, &d_m1i) ||
-        upload(m1_val, sizeof m1_val, &d_m1v) || upload(s0_idx, sizeof s0_idx, &d_s0i) || upload(s0_val, sizeof s0_val, &d_s0v) ||
-        upload(s1_idx, sizeof s1_idx, &d_s1i) || upload(s1_val, sizeof s1_val, &d_s1v)) return 21;
-    gnx_graph_t main_g[2] = {NULL, NULL}, send_g[2] = {NULL, NULL};
+        upload(m1_val, sizeof m1_val, &d_m1v) || upload(pull0_src, sizeof pull0_src, &d_p0s) || upload(push1_idx, sizeof push1_idx, &d_p1i) ||
+        upload(push1_val, sizeof push1_val, &d_p1v)) return 21;
+    gnx_graph_t main_g[2] = {NULL, NULL}, push_g[2] = {NULL, NULL};
     CHECK_GNX(gnx_graph_create_coo(2, 3, 3, (const int64_t *)d_m0i, (const float *)d_m0v, NULL, &main_g[0]));
     CHECK_GNX(gnx_graph_create_coo(2, 3, 3, (const int64_t *)d_m1i, (const float *)d_m1v, NULL, &main_g[1]));
-    CHECK_GNX(gnx_graph_create_coo(1, 2, 1, (const int64_t *)d_s0i, (const float *)d_s0v, NULL, &send_g[0]));
-    CHECK_GNX(gnx_graph_create_coo(1, 2, 1, (const int64_t *)d_s1i, (const float *)d_s1v, NULL, &send_g[1]));
+    CHECK_GNX(gnx_graph_create_coo(1, 2, 1, (const int64_t *)d_p1i, (const float *)d_p1v, NULL, &push_g[1]));
     gnx_halo_plan_t plan[2] = {NULL, NULL};
-    const int64_t one_from[2][2] = {{0, 1}, {1, 0}};                 /* rows received from / sent to rank q, per block */
+    /* rows per peer q, for block r: received as pulled rows / as pushed sums, sent as pulled rows / as pushed sums */
+    const int64_t recv_pull[2][2] = {{0, 0}, {1, 0}}, recv_push[2][2] = {{0, 1}, {0, 0}};
+    const int64_t send_pull[2][2] = {{0, 1}, {0, 0}}, send_push[2][2] = {{0, 0}, {1, 0}};
+    const int32_t *pull_src[2] = {(const int32_t *)d_p0s, NULL};
     float *d_X[2], *d_send[2], *d_out[2];
-    int64_t n_buf[2], local0[2], n_send[2], recv0[2][2], send0[2][2];
+    int64_t n_buf[2], local0[2], n_send[2], n_send_pull[2], recv0[2][2], spull0[2][2], spush0[2][2];
     for (int r = 0; r < 2; ++r) {
-        CHECK_GNX(gnx_halo_plan_create(2, r, 2, one_from[r], one_from[r], send_g[r], &plan[r]));
-        CHECK_GNX(gnx_halo_plan_layout(plan[r], &n_buf[r], &local0[r], &n_send[r], recv0[r], send0[r]));
-        if (n_buf[r] != 3 || n_send[r] != 1 || local0[r] != (r == 0 ? 0 : 1) || recv0[r][1 - r] != (r == 0 ? 2 : 0)) { printf("layout of block %d\n", r); return 22; }
+        CHECK_GNX(gnx_halo_plan_create(2, r, 2, recv_pull[r], recv_push[r], send_pull[r], send_push[r], pull_src[r], push_g[r], &plan[r]));
+        CHECK_GNX(gnx_halo_plan_layout(plan[r], &n_buf[r], &local0[r], &n_send[r], &n_send_pull[r], recv0[r], spull0[r], spush0[r]));
+        if (n_buf[r] != 3 || n_send[r] != 1 || n_send_pull[r] != (r == 0 ? 1 : 0) || local0[r] != (r == 0 ? 0 : 1) || recv0[r][1 - r] != (r == 0 ? 2 : 0)) {
+            printf("layout of block %d\n", r); return 22;
+        }
         CHECK_HIP(hipMalloc((void **)&d_X[r], 3 * C * sizeof(float)));
         CHECK_HIP(hipMalloc((void **)&d_send[r], C * sizeof(float)));
         CHECK_HIP(hipMalloc((void **)&d_out[r], 2 * C * sizeof(float)));
         CHECK_HIP(hipMemset(d_X[r], 0, 3 * C * sizeof(float)));
         CHECK_HIP(hipMemcpy(d_X[r] + local0[r] * C, (const float *)d_H + 2 * r * C, 2 * C * sizeof(float), hipMemcpyDeviceToDevice));
-        CHECK_GNX(gnx_halo_pack(plan[r], d_X[r], C, C, d_send[r], C, NULL));
+        CHECK_GNX(gnx_halo_pack(plan[r], GNX_HALO_PULL, d_X[r], C, C, d_send[r], C, NULL));      /* the two halves, one after the other */
+        CHECK_GNX(gnx_halo_pack(plan[r], GNX_HALO_PUSH, d_X[r], C, C, d_send[r], C, NULL));
     }
-    for (int r = 0; r < 2; ++r)                                      /* the caller's exchange: block r's message lands in the peer's region(r) */
-        CHECK_HIP(hipMemcpy(d_X[1 - r] + recv0[1 - r][r] * C, d_send[r] + send0[r][1 - r] * C, C * sizeof(float), hipMemcpyDeviceToDevice));
+    /* the caller's exchange: block 0's pulled row lands in block 1's region(0), block 1's pushed sum in block 0's region(1) */
+    CHECK_HIP(hipMemcpy(d_X[1] + recv0[1][0] * C, d_send[0] + spull0[0][1] * C, C * sizeof(float), hipMemcpyDeviceToDevice));
+    CHECK_HIP(hipMemcpy(d_X[0] + recv0[0][1] * C, d_send[1] + spush0[1][0] * C, C * sizeof(float), hipMemcpyDeviceToDevice));
     for (int r = 0; r < 2; ++r) {
         float got[2 * C];
         CHECK_GNX(gnx_spmm(main_g[r], NULL, NULL, d_X[r], C, C, (const float *)d_H + 2 * r * C, C, 0.9f, 0.1f, GNX_ACT_NONE, d_out[r], C, NULL));
@@ -78,11 +84,14 @@ static int two_block_plan(void) {
         for (int i = 0; i < 2 * C; ++i)
             if (fabsf(got[i] - want[2 * r * C + i]) > 1e-5f * fabsf(want[2 * r * C + i])) { printf("block %d element %d: got %g want %g\n", r, i, got[i], want[2 * r * C + i]); return 23; }
     }
-    if (gnx_halo_exchange(plan[0], NULL, d_send[0], d_X[0], C, NULL) != GNX_ERR_INVALID) { printf("NULL communicator not refused\n"); return 24; }
+    if (gnx_halo_exchange(plan[0], GNX_HALO_ALL, NULL, d_send[0], d_X[0], C, NULL) != GNX_ERR_INVALID) { printf("NULL communicator not refused\n"); return 24; }
+    if (gnx_halo_pack(plan[0], 7, d_X[0], C, C, d_send[0], C, NULL) != GNX_ERR_INVALID) { printf("invalid part not refused\n"); return 25; }
+    /* no RCCL in this process and none bound: the exchange must say so, not load a library of its own */
+    if (gnx_halo_exchange(plan[0], GNX_HALO_ALL, (void *)plan, d_send[0], d_X[0], C, NULL) != GNX_ERR_UNSUPPORTED) { printf("exchange without RCCL: %s\n", gnx_last_error()); return 26; }
     for (int r = 0; r < 2; ++r) {
         CHECK_GNX(gnx_halo_plan_destroy(plan[r]));
         CHECK_GNX(gnx_graph_destroy(main_g[r]));
-        CHECK_GNX(gnx_graph_destroy(send_g[r]));
+        if (push_g[r]) CHECK_GNX(gnx_graph_destroy(push_g[r]));
     }
     CHECK_GNX(gnx_graph_destroy(whole));
     return 0;

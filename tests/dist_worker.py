@@ -82,6 +82,31 @@ class OracleBackend:
     def gather_rows(self, X, idx):
         return X[idx].contiguous()
 
+    # ---- the exchange plan: the layout rules of gnx_halo_plan_create restated, packing by numpy -------------------------
+    def halo_plan(self, rank, n_local, recv_pull, recv_push, send_pull, send_push, pull_src, push_graph):
+        P = len(recv_pull)
+        plan = type("Plan", (), {})()
+        at, plan.recv_row0 = 0, []
+        for q in range(P):
+            if q == rank:
+                plan.local_row0 = at
+                at += n_local
+            plan.recv_row0.append(at)
+            at += recv_pull[q] + recv_push[q]
+        plan.n_buf, plan.n_send_pull = at, sum(send_pull)
+        plan.n_send = plan.n_send_pull + sum(send_push)
+        plan.send_pull_row0 = [sum(send_pull[:q]) for q in range(P)]
+        plan.send_push_row0 = [plan.n_send_pull + sum(send_push[:q]) for q in range(P)]
+        plan.n_local, plan.pull_src, plan.push_graph = n_local, pull_src.long(), push_graph
+        return plan
+
+    def halo_pack(self, plan, part, buf, send):
+        local = buf[plan.local_row0:plan.local_row0 + plan.n_local]
+        if part != "push" and plan.n_send_pull:
+            send[:plan.n_send_pull] = local[plan.pull_src]
+        if part != "pull" and plan.n_send > plan.n_send_pull:
+            send[plan.n_send_pull:plan.n_send] = torch.from_numpy(self._product(plan.push_graph, None, local))
+
     # ---- edge dropout on a vertex block: the arithmetic of gnx_graph_colsum_streams / gnx_spmm_dropped, in numpy ----
     def set_block(self, g, row0_global, row0_buf, col_gid):
         g.row0_global, g.row0_buf, g.col_gid = int(row0_global), int(row0_buf), col_gid.numpy().astype(np.int64)
@@ -160,7 +185,8 @@ def train_on_blocks(rank, world, dev, backend, graph_dropout=0.0):
     local = lambda ids: ids[(ids >= lo) & (ids < hi)]
     tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
     torch.manual_seed(21)                                          # reset() draws the same initial weights on every rank
-    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4 / world,
+    # train()'s DEFAULT regularization (5e-4): SummedGradients.replicas keeps the summed weight decay at one process's
+    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50,
                 optimizer=lambda params: sharded.SummedGradients(torch.optim.Adam(params, lr=0.01, eps=1e-7), sg.comm))
     got = [v.var.detach().cpu().numpy().astype(np.float64) for v in model.vars()]
     accuracy = model.evaluate(tasks[1])
@@ -231,7 +257,7 @@ def train_gcn_on_blocks(rank, world, dev, backend):
     local = lambda ids: ids[(ids >= lo) & (ids < hi)]
     tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
     torch.manual_seed(5)
-    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4 / world,
+    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4,
                 optimizer=lambda params: sharded.SummedGradients(torch.optim.Adam(params, lr=0.01, eps=1e-7), sg.comm))
     got = [v.var.detach().cpu().numpy().astype(np.float64) for v in model.vars()]
     # ---- one process, dense float64 -------------------------------------------------------------------------------------
@@ -288,7 +314,7 @@ def train_gcnii_on_blocks(rank, world, dev, backend):
     local = lambda ids: ids[(ids >= lo) & (ids < hi)]
     tasks = [sharded.BlockNodeClassification(list(local(ids) - lo), labels[local(ids)], sg.comm) for ids in (train_ids, valid_ids)]
     torch.manual_seed(6)
-    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4 / world,
+    model.train(train=tasks[0], valid=tasks[1], epochs=epochs, patience=50, regularization=5e-4,
                 optimizer=lambda params: sharded.SummedGradients(torch.optim.Adam(params, lr=0.01, eps=1e-7), sg.comm))
     got = [v.var.detach().cpu().numpy().astype(np.float64) for v in model.vars()]
     # ---- one process, dense float64 -------------------------------------------------------------------------------------
@@ -459,6 +485,9 @@ def main():
     assert torch.equal(out, again), "propagate is not repeatable"
     zero = sg.propagate(state, a, 0)
     assert torch.equal(zero, H0), "K = 0 must return H0 in the caller's order"
+    if sg.world > 1:          # pulled rows sent ahead of the pushed partial sums: two messages per peer, the same bytes in the same places
+        early = sg.propagate(state, a, K, early_pull=True)
+        assert torch.equal(early, out), "early_pull changed the result"
     if mode not in ("slices", "directed"):                          # symmetric unit-weight graphs: bench.py's in-run self check
         assert sg.fixed_point_error(sg.make_state(H0.clone()), a, K) < 1e-5      # (overwrites the H0 it is given)
     one = sg.propagate(sg.make_state(H0, chunks=1) if sg.world > 1 else state, a, K)

@@ -483,6 +483,48 @@ def test_dropped_adjacency_fused_into_spmm_bitwise(gnntf, C):
     assert not isinstance(gnntf.sparse.dropped_adjacency(dup, 0.5, 1, 1), DroppedAdjacency)
 
 
+def test_fused_dropout_skips_dropped_entries_even_when_their_row_is_not_finite(gnntf):
+    """Pins the stated precondition of gnx_spmm_dropped (gnx.h; DroppedAdjacency): a dropped entry is SKIPPED, so a non-finite row
+    of X behind it does not reach the sum, while the materialised form (an explicit zero weight, as tf.nn.dropout leaves in
+    G.values, layered.py:50) turns 0 * inf into NaN exactly like the oracle does.  Finite rows: the two forms stay bitwise equal."""
+    from gnntf.sparse import _launch
+    n, C = 600, 16
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 6000, seed=12)
+    g = make_graph(gnntf, coo, vals, shape)
+    fused = gnntf.sparse.dropped_adjacency(g, 0.5, 5, 2)
+    two_pass = gnntf.normalize(g, "symmetric", "none", dropout=0.5, seed=5, stream_id=2)
+    rowptr, colidx, _ = (t.cpu().numpy() for t in g.csr_arrays())
+    w = two_pass.vals.cpu().numpy()
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    col = int(colidx[np.nonzero(w == 0)[0][0]])                      # a column with at least one dropped entry
+    X = np.random.default_rng(0).standard_normal((n, C)).astype(np.float32)
+    X[col] = np.inf
+    a = _launch(fused, dev(X), None, 1.0, 0.0, 0).cpu().numpy()
+    b = _launch(two_pass, dev(X), None, 1.0, 0.0, 0).cpu().numpy()
+    dropped_only = np.setdiff1d(rows[(colidx == col) & (w == 0)], rows[(colidx == col) & (w != 0)])      # rows that reach `col` through dropped entries only
+    kept = np.unique(rows[(colidx == col) & (w != 0)])
+    assert len(dropped_only) > 0
+    assert np.isfinite(a[dropped_only]).all() and np.isnan(b[dropped_only]).all()      # skipped vs explicit zero times inf
+    assert np.isinf(a[kept]).all() and not np.isfinite(b[kept]).any()                  # a kept entry carries the inf in both forms
+    ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=0.5, training=True, seed=5, stream=2)
+    with np.errstate(invalid="ignore"):
+        want = orc.sparse_dense_matmul(ai, av, shape, X)
+    assert np.isnan(want[dropped_only]).all()                                            # the reference's behaviour = the materialised form's
+    untouched = np.setdiff1d(np.arange(n), rows[colidx == col])
+    assert np.array_equal(a[untouched], b[untouched])
+
+
+def test_linear_combination_accepts_unaligned_views(gnntf):
+    """A contiguous view with a storage offset (a row slice that starts 4 bytes into an allocation) is a legal gradient for the K-loop
+    backward; gnx_linear_combination itself wants 16-byte aligned pointers, so such terms are copied first."""
+    base = torch.arange(4 * 7 + 1, dtype=torch.float32, device="cuda")
+    t = base[1:].reshape(4, 7)
+    assert t.is_contiguous() and t.data_ptr() % 16 != 0
+    u = torch.ones(4, 7, device="cuda")
+    out = gnntf.sparse.linear_combination([(t, 2.0), (u, -1.0), (t, 0.5)])
+    assert torch.equal(out, t * 2.0 - u + t * 0.5)
+
+
 def test_degree_scales_of_k_streams_in_one_pass(gnntf):
     """gnx_graph_colsum_streams: the column sums of K dropout streams from one pass over the structure == K separate
     gnx_graph_colsum calls, bit for bit (hub columns included; duplicates take the per-stream path), and against the oracle."""

@@ -59,10 +59,19 @@ class ThreadComm:
         return parts
 
     def exchange(self, send_chunks, recv_chunks):
-        sends = self._gather(list(send_chunks))
-        for q, dst in enumerate(recv_chunks):
-            if q != self.rank and dst is not None and dst.numel() > 0:
-                dst.copy_(sends[q][self.rank])
+        self.exchange_pairs([(q, t) for q, t in enumerate(send_chunks) if q != self.rank],
+                            [(q, t) for q, t in enumerate(recv_chunks) if q != self.rank])
+
+    def exchange_pairs(self, sends, recvs):
+        """Several messages per peer are matched in list order, as a group of point-to-point transfers would."""
+        posted = self._gather([(q, t) for q, t in sends if t is not None and t.numel() > 0])
+        taken = [0] * self.size
+        for q, dst in recvs:
+            if dst is None or dst.numel() == 0:
+                continue
+            mine = [t for to, t in posted[q] if to == self.rank]
+            dst.copy_(mine[taken[q]])
+            taken[q] += 1
         self._done()
 
     def barrier(self):

@@ -45,7 +45,10 @@ class LoopbackComm(sharded.Comm):
         return t
 
     def exchange(self, send_chunks, recv_chunks):
-        for s, r in zip(send_chunks, recv_chunks):      # about the same sizes by symmetry: stand in for the peer's rows
+        self.exchange_pairs(list(enumerate(send_chunks)), list(enumerate(recv_chunks)))
+
+    def exchange_pairs(self, sends, recvs):
+        for (_, s), (_, r) in zip(sends, recvs):        # about the same sizes by symmetry: stand in for the peer's rows
             if s is not None and r is not None:
                 m = min(s.shape[0], r.shape[0])
                 r[:m].copy_(s[:m])
@@ -151,6 +154,8 @@ def main():
         "interior_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=True, skip_empty=True) for c in every]),
         "boundary_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=False, skip_empty=True) for c in every]),
         "pack": part_ms(lambda: [sg._pack(state, c, state.bufs[c][1]) for c in every]),
+        "pack_pulled_rows": part_ms(lambda: [sg._pack(state, c, state.bufs[c][1], "pull") for c in every]),
+        "pack_pushed_sums": part_ms(lambda: [sg._pack(state, c, state.bufs[c][1], "push") for c in every]),
         "first_iterations_interior_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=True, skip_empty=False) for c in every]),
     }
     sg.propagate(state, 0.1, 10)
