@@ -41,8 +41,11 @@ def parse():
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--grid", type=str, default="", help="PVxPF process grid (vertex blocks x feature slices); default Nx1")
-    ap.add_argument("--cover", choices=["cover", "pull"], default="cover", help="halo plan: pull/push vertex cover or plain pull")
-    ap.add_argument("--chunks", type=int, default=2, help="column chunks whose exchange and SpMM overlap")
+    ap.add_argument("--cover", choices=["auto", "cover", "pull"], default="auto",
+                    help="halo plan: pull/push vertex cover, plain pull, or auto = one step of each is timed before the run and the faster one kept")
+    ap.add_argument("--chunks", type=int, default=0, help="column chunks whose exchange and SpMM overlap (0 = auto: 1, 2 and 4 are tried)")
+    ap.add_argument("--early-pull", choices=["auto", "on", "off"], default="auto",
+                    help="send the pulled rows ahead of the pushed partial sums (two messages per peer); auto = tried both ways")
     ap.add_argument("--whole-rows", action="store_true", help="do not split interior / boundary rows")
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
@@ -172,7 +175,7 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak):
     achieved = counted / launch_s / 1e9
     rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": source, "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
-           "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K, "alg_GBs": b_alg / launch_s / 1e9,
+           "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K,
            "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if measured_peak else None,
            "measured_read_peak": MEASURED_READ_PEAK[0],
            "frac_of_measured_read_peak": (achieved / MEASURED_READ_PEAK[0]) if MEASURED_READ_PEAK[0] else None,
@@ -183,42 +186,77 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak):
     return rec
 
 
-# ---- CPU baseline: the oracle's C port on a bounded sample -------------------------------------------
-def cpu_baseline(g, H0, args):
+# ---- CPU baselines on a bounded sample: SURVEY.md 8(d) (i) scipy, one thread; (ii) torch.sparse.mm, all threads; (iii) C / OpenMP port ----
+def cpu_baseline(g, adj, H0, args):
+    """One of the K iterations over a row prefix of the SAME workload, three ways (every cost is linear in the entries walked, the
+    gathers span all of H).  ``value`` is the strongest of the three that does what the reference does -- the C / OpenMP port with
+    the per-iteration renormalisation (gnn.py:36-50 called from filter.py:18): whole-graph normalisation timed once over all
+    entries, SpMM + mix on the sample and scaled to all entries, value = nnz / (t_norm + t_spmm * nnz / e)."""
     import numpy as np
+    import torch
     import __graft_entry__ as ge
+    from oracle import cpu_baselines as cb
     lib = ctypes.CDLL(ge.build_oracle())
     sig = [ctypes.c_int64, ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int]
     lib.oracle_sample_iteration_par.restype = ctypes.c_int
     lib.oracle_sample_iteration_par.argtypes = sig
     lib.oracle_num_threads.restype = ctypes.c_int
     rowptr, colidx, vals = (t.cpu().numpy() for t in g.csr_arrays())
+    nvals = adj.vals.cpu().numpy()                                                # A_hat's values (device normalisation)
     H = H0.cpu().numpy()
     n, C = H.shape
     nnz = int(rowptr[-1])
+    budget = max(args.cpu_seconds, 3.0)
 
     def run(rows, renorm=1):
         out = np.empty((max(rows, 1), C), dtype=np.float32)
+        given = vals if renorm else nvals                                         # renorm = 0: the values are A_hat's already
         t0 = time.time()
-        rc = lib.oracle_sample_iteration_par(n, rows, rowptr.ctypes.data, colidx.ctypes.data, vals.ctypes.data, H.ctypes.data,
+        rc = lib.oracle_sample_iteration_par(n, rows, rowptr.ctypes.data, colidx.ctypes.data, given.ctypes.data, H.ctypes.data,
                                              H.ctypes.data, args.alpha, C, out.ctypes.data, renorm)
         assert rc == 0
-        return time.time() - t0, int(rowptr[rows])
+        return time.time() - t0, int(rowptr[rows]), out
 
-    probe_rows = min(n, 100_000)
-    t_probe, e_probe = run(probe_rows, renorm=0)                   # SpMM + mix alone on a probe
-    t_norm, _ = run(0)                                            # the whole-graph renormalisation alone
-    rate = max(e_probe, 1) / max(t_probe, 1e-3)
-    rows = int(min(n, max(probe_rows, max(args.cpu_seconds - t_norm, 1.0) * rate / max(nnz / n, 1e-9))))
-    t, e = run(rows)
-    t_only, _ = run(rows, renorm=0)
-    return {"value": e / t, "unit": "edges/s", "cores": int(lib.oracle_num_threads()), "kind": "port",
+    def rows_for(rate, seconds, floor):
+        """Row prefix whose entries take about ``seconds`` at ``rate`` entries/s."""
+        want = int(min(nnz, max(floor, seconds * rate)))
+        return int(min(n, max(1, np.searchsorted(rowptr, want, side="left"))))
+
+    # (iii) the oracle's C / OpenMP port, all host threads
+    probe_rows = rows_for(1.0, 0.0, min(nnz, 2_000_000))
+    t_probe, e_probe, _ = run(probe_rows, renorm=0)
+    t_norm, _, _ = run(0)                                                         # the whole-graph renormalisation alone
+    rows = rows_for(e_probe / max(t_probe, 1e-3), 0.4 * budget, e_probe)
+    t_only, e, ref_out = run(rows, renorm=0)
+    port = {"value": nnz / (t_norm + t_only * nnz / e), "unit": "edges/s", "cores": int(lib.oracle_num_threads()), "kind": "port",
             "spmm_only_value": e / t_only,
-            "sample": f"1 of {args.iterations} iterations over the first {rows} of {n} rows ({e} entries, C={C}): value includes the "
-                      f"per-iteration whole-graph renormalisation the reference does (gnn.py:36-50 called from filter.py:18; "
-                      f"{t_norm:.1f} s of the {t:.1f} s, all threads), spmm_only_value is the same rows with the adjacency "
-                      f"normalised beforehand (what the GPU figure times; {t_only:.1f} s); CPU restatement of gnntf's TF-CPU path "
-                      f"(TensorFlow unavailable)"}
+            "sample": f"C / OpenMP port of the oracle (oracle/propagate_ref.c), all host threads: 1 of {args.iterations} iterations; the whole-graph "
+                      f"renormalisation the reference does in every iteration (gnn.py:36-50 called from filter.py:18) timed over all {nnz} "
+                      f"entries ({t_norm:.2f} s), SpMM + mix over the first {rows} of {n} rows ({e} entries, C={C}: {t_only:.2f} s) and scaled "
+                      f"to all entries: value = nnz / (t_norm + t_spmm * nnz / e); spmm_only_value = e / t_spmm with the adjacency "
+                      f"normalised beforehand (what the GPU figure times); CPU restatement of gnntf's TF-CPU path (TensorFlow unavailable)"}
+    # (i) scipy CSR on ONE thread, re-normalising inside the iteration (sample-sized: its cost is linear in the entries too)
+    rows1 = rows_for(2e6, 0.0, min(nnz, 1_000_000))
+    _, tn, ts = cb.scipy_iteration(rowptr, colidx, vals, H, H, args.alpha, rows1)
+    e1 = int(rowptr[rows1])
+    rows1 = rows_for(e1 / max(tn + ts, 1e-3), 0.35 * budget, e1)
+    _, tn, ts = cb.scipy_iteration(rowptr, colidx, vals, H, H, args.alpha, rows1)
+    e1 = int(rowptr[rows1])
+    port["scipy_single_thread"] = {"value": e1 / (tn + ts), "unit": "edges/s", "cores": 1, "kind": "port", "spmm_only_value": e1 / ts,
+                                   "sample": f"scipy.sparse CSR @ dense, float32, one thread (oracle/cpu_baselines.py): first {rows1} rows ({e1} entries): "
+                                             f"column sums + divide_no_nan + two value scalings of those entries {tn:.2f} s, SpMM + mix {ts:.2f} s"}
+    # (ii) torch.sparse.mm on all host threads, adjacency normalised beforehand
+    rows2 = rows_for(e / t_only / 4, 0.25 * budget, min(nnz, 2_000_000))
+    out2, t2, used = cb.torch_sparse_iteration(rowptr, colidx, nvals, H, H, args.alpha, rows2)
+    e2 = int(rowptr[rows2])
+    agree = None
+    if rows2 <= rows:                                                            # same rows, same values: the two restatements must agree
+        agree = float(np.abs(out2 - ref_out[:rows2]).max())
+    port["torch_sparse_all_threads"] = {"value": e2 / t2, "unit": "edges/s", "cores": int(used), "kind": "port",
+                                        "sample": f"torch.sparse.mm (CPU, COO, {used} threads) + mix over the first {rows2} rows ({e2} entries), adjacency "
+                                                  f"normalised beforehand: {t2:.2f} s; max |difference| to the C port on those rows: {agree}"}
+    port["host"] = {"os_cpu_count": os.cpu_count(), "torch_threads": int(torch.get_num_threads())}
+    return port
 
 
 # ---- secondary workloads (N = 1): timed in this same run so that they are driver-timed too ----------------
@@ -262,6 +300,41 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
             widths.append(rec)
         del H0, res, work
     out["config4_graph_other_widths"] = widths
+    # the same propagation through the API the north star names: architecture.predict() of gnntf.APPNP (filter.py:25-35 ->
+    # trainable.py:26-29) on the config-4 graph.  APPNP builds [Dropout, Dense(F -> C), PPRLoop]; the PPRLoop layer's forward, called
+    # through the Layer protocol in eval mode, is the K = 10 propagation at width C and must cost what gnx_appnp_propagate costs
+    via_api = []
+    for C in ([] if skip_config4 else [c4]) + [8]:
+        gnntf.set_seed(0)
+        F = 64
+        X = torch.randn(n, F, device=device)
+        model = gnntf.APPNP(g, X, num_classes=C, latent_dims=[], iterations=K, a=a)
+        model.training_mode(False)
+        nodes = torch.randperm(n, device=device)[:100_000]
+        task = gnntf.NodeClassification(nodes)
+
+        def predict():
+            model._fast_predict = None                           # trainable.py:22-24: what reset() clears; every call recomputes
+            return model.predict(task)
+        loop = model.layers()[-1]
+        with torch.no_grad():
+            t_predict = median_ms(predict, reps=3, warm=1)
+            H0 = loop.H0.value
+            t_loop = median_ms(lambda: loop(model, H0), reps=3, warm=1)
+            kernel = g.last_kernel()
+            res, work = torch.empty_like(H0), torch.empty_like(H0)
+            t_direct = median_ms(lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(res),
+                                                                           nat.ptr(work), nat.current_stream())), reps=3, warm=1)
+            same = bool(torch.equal(loop.value, res))
+        via_api.append({"C": C, "layers": [type(l).__name__ for l in model.layers()], "predict_ms": t_predict, "ppr_loop_layer_ms": t_loop,
+                        "gnx_appnp_propagate_ms": t_direct, "layer_over_direct": t_loop / t_direct, "bitwise_equal": same, "kernel": kernel,
+                        "edges_per_s_layer": nnz * K / t_loop * 1e3,
+                        "what": f"gnntf.APPNP(graph, X[N, {F}], num_classes={C}, latent_dims=[]) in eval mode: predict_ms = architecture.predict(NodeClassification("
+                                f"100k nodes)) with the memo cleared (Dense {F} -> {C} on the matrix cores + K = {K} propagation + gather/argmax); "
+                                f"ppr_loop_layer_ms = the PPRLoop layer's forward alone; gnx_appnp_propagate_ms = the C entry on the same H0"})
+        del model, X, H0, res, work, task, nodes, loop
+        torch.cuda.empty_cache()
+    out["config4_via_layer_api"] = via_api
     # training-mode step: K = 10 iterations, each with its own dropped + re-normalised adjacency,
     # forward + backward through the fused loop node (masks regenerated in the backward), C = 64
     C = 64
@@ -420,31 +493,95 @@ def main():
         note(f"graph built: {g.n_rows} rows / {g.nnz} entries, prep {prep}")
         gen = torch.Generator(device=device).manual_seed(2)
         H0 = torch.rand(n_local, C, device=device, generator=gen) * 2 - 1       # U(-1, 1), seed 2
-        out = torch.empty_like(H0)
-        work = torch.empty_like(H0)
         from gnntf import _native as nat
         lib = nat.lib()
+        # The timed step goes through the API the north star names: the propagation layer of gnntf.APPNP (filter.py:25-35), called
+        # through the Layer protocol in eval mode exactly as architecture.predict() calls it (trainable.py:26-29 -> layered.py:52-55).
+        # H0 stands for the pre-MLP's output: it is planted as the value of the Dense layer the loop reads.
+        gnntf.set_seed(0)
+        model = gnntf.APPNP(g, torch.zeros(n_local, 1, device=device), num_classes=C, latent_dims=[], iterations=K, a=a)
+        model.training_mode(False)
+        loop = model.layers()[-1]
+        assert isinstance(loop, gnntf.PPRLoop)
+        loop.H0.value = H0
+        api = {"timed_call": "PPRLoop.__call__(architecture, H0) -- the layer gnntf.APPNP(...) builds for filter.py:34-35, eval mode, torch.no_grad()",
+               "layers": [type(l).__name__ for l in model.layers()]}
+        adj = model.get_adjacency(0.5)                                          # the cached eval-mode adjacency the layer uses (A2 once)
 
         def step():
-            nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(out), nat.ptr(work),
-                                              nat.current_stream()))
+            loop.value = None                                                   # (the previous result: 41 GB at config 5)
+            with torch.no_grad():
+                loop(model, H0)
         halo = None
         C_local = C
     else:
-        from gnntf import sharded
-        sg, prep, (gv, gf, pv, pf) = sharded.build_rmat_blocks(args.nodes, args.entries, seed=1, device=device, grid=(pv, pf),
-                                                              cover=args.cover, chunks=args.chunks, split_rows=not args.whole_rows,
-                                                              relabel=True)
-        n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
-        note(f"vertex blocks built: {pv} x {pf} grid, {n_local} rows / {nnz_local} entries on rank 0, prep {prep}")
+        from gnntf import rmat, sharded
+        idx, vals, bounds, comm, (gv, gf, pv, pf), t_gen = rmat.rmat_block_entries(args.nodes, args.entries, seed=1, device=device, grid=(pv, pf))
         C_local = C // pf                                                       # this rank's feature slice
         gen = torch.Generator(device=device).manual_seed(2 + rank)
+        # Which halo plan / pipelining is fastest depends on what the links of THIS node sustain, which nothing on a one-GPU box
+        # can tell: one step of every variant is timed before the timed region (max over ranks) and the timed steps run on the
+        # fastest.  cover: pull/push vertex cover or the classic pull-only halo; chunks: column chunks whose exchange and SpMM
+        # overlap; early_pull: the pulled rows leave as soon as they are gathered, ahead of the pushed partial sums.
+        covers = ["cover", "pull"] if args.cover == "auto" else [args.cover]
+        if pv == 1:
+            covers = covers[:1]                                                 # one vertex block: nothing is exchanged
+        chunk_options = [k for k in (1, 2, 4) if k <= max(C_local // 32, 1)] if args.chunks <= 0 else [args.chunks]
+        t0 = time.time()
+        graphs = {cover: sharded.ShardedGraph(idx, vals, bounds, comm=comm, cover=cover, chunks=chunk_options[-1],
+                                              split_rows=not args.whole_rows, relabel=True) for cover in covers}
+        del idx, vals
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        prep = dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2), plans_built=covers)
+        sg = graphs[covers[0]]
+        n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
+        note(f"vertex blocks built: {pv} x {pf} grid, {n_local} rows / {nnz_local} entries on rank 0, prep {prep}")
         H0 = torch.rand(n_local, C_local, device=device, generator=gen) * 2 - 1
-        state = sg.make_state(H0)
+
+        def rank_max_ms(fn, reps=2):
+            """Slowest rank's time of one call of ``fn`` (best of ``reps``), barrier + synchronize on both sides."""
+            best = None
+            for _ in range(reps):
+                dist.barrier(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                best = float(t.item()) if best is None else min(best, float(t.item()))
+            return best * 1e3
+
+        variants = []
+        if sg.world > 1 and (len(covers) > 1 or len(chunk_options) > 1 or args.early_pull == "auto"):
+            for cover in covers:
+                cand = graphs[cover]
+                earlies = [False, True] if (args.early_pull == "auto" and cand.n_send_push_max > 0 and cand.n_send_pull_max > 0) \
+                    else [args.early_pull == "on"]
+                for chunks in chunk_options:
+                    state = cand.make_state(H0, chunks=chunks)
+                    for early in earlies:
+                        run = lambda: cand.propagate(state, a, K, early_pull=early)
+                        run()                                                   # opens the connections / sizes the scratch of this variant
+                        variants.append(dict(cover=cover, chunks=chunks, early_pull=early, step_ms=rank_max_ms(run)))
+                        note(f"variant {variants[-1]}")
+                    del state
+                    torch.cuda.empty_cache()
+            best = min(variants, key=lambda v: v["step_ms"])                     # the same numbers on every rank: the same choice
+        else:
+            best = dict(cover=covers[0], chunks=chunk_options[-1] if args.chunks <= 0 else args.chunks, early_pull=args.early_pull == "on")
+        sg = graphs[best["cover"]]
+        for cover in covers:
+            if cover != best["cover"]:
+                del graphs[cover]
+        torch.cuda.empty_cache()
+        state = sg.make_state(H0, chunks=best["chunks"])
 
         def step():
-            sg.propagate(state, a, K)
+            sg.propagate(state, a, K, early_pull=best["early_pull"])
         halo = sg.halo_stats()
+        halo.update(chunks=best["chunks"], early_pull=best["early_pull"], variants_timed_before_the_run=variants,
+                    chosen=dict(best), pull_rows_sent=sg.n_send_pull_max, push_rows_sent=sg.n_send_push_max)
 
     def barrier():
         if sharded_path:
@@ -472,14 +609,24 @@ def main():
     if sharded_path:
         check_err = sg.fixed_point_error(state, a, K)
     else:
+        # the C entry on the same H0: what the layer call must cost, and bit for bit what it must return
+        out, work = torch.empty_like(H0), torch.empty_like(H0)
+        direct = lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(out), nat.ptr(work),
+                                                           nat.current_stream()))
+        api["gnx_appnp_propagate_ms_per_step"] = median_ms(direct, reps=3, warm=1)
+        api["layer_ms_per_step"] = sum(step_ms) / len(step_ms)
+        api["bitwise_equal_to_c_entry"] = bool(torch.equal(loop.value, out))
+        loop.value = None
         deg = torch.empty(g.n_rows, dtype=torch.float32, device=device)
         nat.check(lib.gnx_graph_colsum(g.handle, 0.0, 0, 0, nat.ptr(deg), nat.current_stream()))
         E0 = deg.sqrt()[:, None] * (1.0 + torch.arange(C, dtype=torch.float32, device=device) / C)[None, :]
         del deg
-        nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(E0), a, K, C, nat.ptr(out), nat.ptr(work),
-                                          nat.current_stream()))
+        loop.H0.value = E0
+        with torch.no_grad():
+            loop(model, E0)
         from gnntf.sharded import max_relative_deviation
-        check_err = max_relative_deviation(out, E0)
+        check_err = max_relative_deviation(loop.value, E0)
+        loop.value, loop.H0.value = None, H0
         del E0
     self_check = {"what": "H0 = sqrt(degree) x s_c is a fixed point of H <- (1-a) A_hat H + a H0 on a symmetric graph: largest deviation "
                           "after K iterations through the timed path, relative to max(|H0|, 1), max over ranks",
@@ -550,16 +697,17 @@ def main():
                        "stored_entries_per_rank": nnz_local, "features": C, "iterations": K, "alpha": a,
                        "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (kernel_blocks if sharded_path else g.last_kernel()),
+                       "api": (None if sharded_path else api),
                        "alt_grid_feature_slices": alt, "self_check": self_check},
             "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:
-            note("CPU baseline (oracle port, bounded sample)")
-            result["cpu_baseline"] = cpu_baseline(g, H0, args)
+            note("CPU baselines (C / OpenMP port, scipy on one thread, torch.sparse on all threads; bounded samples)")
+            result["cpu_baseline"] = cpu_baseline(g, adj, H0, args)
         else:
             result["cpu_baseline"] = None
         if not sharded_path and not args.no_secondary:
-            del g, adj, H0, out, work
+            del g, adj, H0, out, work, model, loop
             torch.cuda.empty_cache()
             note("secondary workloads")
             result["secondary"] = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4")

@@ -708,16 +708,36 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
     }
 }
 
-// float4 grid-stride copy, four independent 16-byte loads in flight per lane: the achievable-HBM-bandwidth
-// yardstick bench.py measures beside the SpMM
-__global__ __launch_bounds__(256) void k_stream_copy(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+// The HBM yardsticks bench.py measures beside the SpMM (gnx_stream_copy / gnx_stream_read): every block walks tiles of
+// blockDim.x * U float4, U independent 16-byte non-temporal loads in flight per lane (each wave instruction moves 1 KiB of
+// consecutive bytes), non-temporal stores.  Launch shape from tools/stream_bench.hip's sweep on this box.
+constexpr int STREAM_U = 8, STREAM_THREADS = 512, STREAM_BLOCKS = 256 * 4;
+template <bool COPY>
+__global__ __launch_bounds__(STREAM_THREADS) void k_stream(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4,
+                                                           float *__restrict__ sink) {
+    const int64_t tile = (int64_t)blockDim.x * STREAM_U;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int64_t base = (int64_t)blockIdx.x * tile;
+    for (; base + tile <= n4; base += (int64_t)gridDim.x * tile) {
+        f32x4 v[STREAM_U];
+#pragma unroll
+        for (int u = 0; u < STREAM_U; ++u) v[u] = __builtin_nontemporal_load(src + base + (int64_t)u * blockDim.x + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < STREAM_U; ++u) {
+            if (COPY) __builtin_nontemporal_store(v[u], dst + base + (int64_t)u * blockDim.x + threadIdx.x);
+            else acc += v[u];
+        }
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    for (int64_t i = base + threadIdx.x; i < n4; i += blockDim.x) {      // the one ragged tile: exactly one block has base < n4 here
+        if (COPY) dst[i] = src[i];
+        else acc += src[i];
+    }
+    if (!COPY) {
+        float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) atomicAdd(sink + blockIdx.x % 64, v);
+    }
 }
 
 // out = sum_j coef[j] * src[j], elementwise over up to 16 equally long arrays, summed in index order (fixed rounding): the
@@ -751,23 +771,6 @@ __global__ __launch_bounds__(256) void k_lincomb(LinComb a, int64_t n4, int64_t 
         for (int j = 1; j < a.k; ++j) acc = fmaf(a.src[j][i], a.coef[j], acc);
         out[i] = acc;
     }
-}
-
-// read-only counterpart: every lane keeps four 16-byte loads in flight and folds them into one float per block -- the SpMM is
-// almost all reads, so this is the closer yardstick for it
-__global__ __launch_bounds__(256) void k_stream_read(const f32x4 *__restrict__ src, int64_t n4, float *__restrict__ sink) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        acc += (a + b) + (c + d);
-    }
-    for (; i < n4; i += stride) acc += src[i];
-    float v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(sink + blockIdx.x % 64, v);
 }
 
 inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -1213,7 +1216,8 @@ int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *st
     GNX_CHECK_ARG(n_floats >= 0 && n_floats % 4 == 0, "gnx_stream_copy: the length must be a multiple of 4 floats");
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_dst && aligned(d_src, 16) && aligned(d_dst, 16), "gnx_stream_copy: NULL or unaligned pointer");
-    hipLaunchKernelGGL(k_stream_copy, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst, n_floats / 4);
+    hipLaunchKernelGGL(k_stream<true>, dim3(STREAM_BLOCKS), dim3(STREAM_THREADS), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst,
+                       n_floats / 4, (float *)nullptr);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
@@ -1240,7 +1244,8 @@ int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void 
     GNX_CHECK_ARG(n_floats >= 0 && n_floats % 4 == 0, "gnx_stream_read: the length must be a multiple of 4 floats");
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_sink64 && aligned(d_src, 16), "gnx_stream_read: NULL or unaligned pointer");
-    hipLaunchKernelGGL(k_stream_read, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, n_floats / 4, d_sink64);
+    hipLaunchKernelGGL(k_stream<false>, dim3(STREAM_BLOCKS), dim3(STREAM_THREADS), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)nullptr,
+                       n_floats / 4, d_sink64);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }

@@ -53,11 +53,11 @@ def rmat_relabelled_pairs(n, m_undirected, seed, device, perm_seed=3):
     return u, v
 
 
-def build_rmat_blocks(n_global, entries_global, seed, device, backend=None, group=None, grid=None, **graph_options):
-    """STRONG-scaling workload: ONE global R-MAT graph (n_global vertices, entries_global stored entries -- the
-    same graph for every world size, and the graph bench.py's one-GPU run builds) cut into pv contiguous vertex
+def rmat_block_entries(n_global, entries_global, seed, device, group=None, grid=None):
+    """This rank's entries of the STRONG-scaling workload: ONE global R-MAT graph (n_global vertices, entries_global stored
+    entries -- the same graph for every world size, and the graph bench.py's one-GPU run builds) cut into pv contiguous vertex
     blocks.  Rank 0 generates the edge list and broadcasts it; every rank keeps the entries of its rows.
-    Returns (ShardedGraph, info, (v, f, pv, pf))."""
+    Returns (idx int64 [m, 2] global (row, col), vals, bounds, comm of the vertex partition, (v, f, pv, pf), seconds)."""
     world_comm = Comm(group=group) if dist.is_initialized() else Comm(solo=True)
     rank, world = world_comm.rank, world_comm.size
     pv, pf = grid if grid is not None else (world, 1)
@@ -80,14 +80,19 @@ def build_rmat_blocks(n_global, entries_global, seed, device, backend=None, grou
     vals = torch.ones(idx.shape[0], dtype=torch.float32, device=device)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
-    t_gen = time.time() - t0
+    return idx, vals, bounds, comm, (v, f, pv, pf), time.time() - t0
+
+
+def build_rmat_blocks(n_global, entries_global, seed, device, backend=None, group=None, grid=None, **graph_options):
+    """rmat_block_entries + the ShardedGraph over them.  Returns (ShardedGraph, info, (v, f, pv, pf))."""
+    idx, vals, bounds, comm, where, t_gen = rmat_block_entries(n_global, entries_global, seed, device, group=group, grid=grid)
     t0 = time.time()
     sg = ShardedGraph(idx, vals, bounds, backend=backend, comm=comm, **graph_options)
     del idx, vals
     if device.type == "cuda":
         torch.cuda.synchronize(device)
         torch.cuda.empty_cache()
-    return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2)), (v, f, pv, pf)
+    return sg, dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2)), where
 
 
 def build_rmat_shard(nodes_per_rank, entries_per_rank, seed, device, backend=None, group=None, grid=None, relabel=True,

@@ -981,7 +981,8 @@ class ShardedGraph:
 # make `import gnntf.rmat` fail on a half-initialised gnntf.sharded.
 _MOVED = {name: "sharded_layers" for name in ("BlockNodeClassification", "ShardedGCNIILayer", "ShardedGCNLayer", "ShardedPPRLoop",
                                               "SummedGradients")}
-_MOVED.update({name: "rmat" for name in ("build_rmat_blocks", "build_rmat_shard", "rmat_relabelled_pairs", "rmat_undirected_keys")})
+_MOVED.update({name: "rmat" for name in ("build_rmat_blocks", "build_rmat_shard", "rmat_block_entries", "rmat_relabelled_pairs",
+                                         "rmat_undirected_keys")})
 
 
 def __getattr__(name):

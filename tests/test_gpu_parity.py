@@ -704,6 +704,20 @@ def test_fused_ppr_loop_equals_layers(gnntf):
         ev = model.layers()[-1](model, H0.detach())
     adj = model.get_adjacency(0.5)
     assert torch.equal(ev, gnntf.appnp_propagate(adj, H0.detach(), 0.1, 10))
+    # what a user gets without asking: the loop layer whenever filter.py's defaults are in force, the K layers otherwise
+    default = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7)
+    assert isinstance(default.layers()[-1], gnntf.PPRLoop) and not any(isinstance(l, gnntf.PPRIteration) for l in default.layers())
+    by_layer = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, activation=gnntf.relu)
+    assert sum(isinstance(l, gnntf.PPRIteration) for l in by_layer.layers()) == 10
+    with pytest.raises(Exception, match="identity activation"):
+        gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, activation=gnntf.relu, fused=True)
+    # predict() through the default model == the layer-by-layer model with the same weights (eval mode), bit for bit
+    ref = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, fused=False)
+    for v, w in zip(default.vars(), ref.vars()):
+        w.assign(v.identity())
+    default.training_mode(False); ref.training_mode(False)
+    with torch.no_grad():
+        assert torch.equal(default(default.features), ref(ref.features))
 
 
 def test_train_and_predict_end_to_end(gnntf):
@@ -840,3 +854,17 @@ def test_chained_training_forward_equals_step_loop(gnntf, C):
     for ai, av in adjs:
         ref = orc.ppr_iteration(ai, av, shape, ref, H0.cpu().numpy().astype(np.float64), a)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [4, 4 * 512 * 8 * 3, 4 * (512 * 8 * 1024 * 2 + 12345), 4 * 999_983])
+def test_stream_yardsticks_move_every_element(gnntf, n):
+    """gnx_stream_copy / gnx_stream_read (bench.py's measured-peak yardsticks): whole tiles, ragged tails and lengths below one tile."""
+    from gnntf import _native as nat
+    src = torch.arange(n, dtype=torch.float32, device="cuda") % 1024
+    dst = torch.full_like(src, -1.0)
+    nat.check(nat.lib().gnx_stream_copy(nat.ptr(src), nat.ptr(dst), n, nat.current_stream()))
+    assert torch.equal(src, dst)
+    sink = torch.zeros(64, dtype=torch.float32, device="cuda")
+    ones = torch.ones(n, dtype=torch.float32, device="cuda")
+    nat.check(nat.lib().gnx_stream_read(nat.ptr(ones), n, nat.ptr(sink), nat.current_stream()))
+    assert float(sink.double().sum()) == n                      # per-wave sums of ones are exact; the 64 slots hold them all
