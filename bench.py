@@ -560,10 +560,11 @@ def main():
                     else [args.early_pull == "on"]
                 for chunks in chunk_options:
                     state = cand.make_state(H0, chunks=chunks)
+                    alone = dict(exchange_ms_alone=cand.time_exchange(state, repeats=2) * 1e3, compute_ms_alone=cand.time_compute(state, a, repeats=2) * 1e3)
                     for early in earlies:
                         run = lambda: cand.propagate(state, a, K, early_pull=early)
                         run()                                                   # opens the connections / sizes the scratch of this variant
-                        variants.append(dict(cover=cover, chunks=chunks, early_pull=early, step_ms=rank_max_ms(run)))
+                        variants.append(dict(cover=cover, chunks=chunks, early_pull=early, step_ms=rank_max_ms(run), **alone))
                         note(f"variant {variants[-1]}")
                     del state
                     torch.cuda.empty_cache()
@@ -617,6 +618,8 @@ def main():
         api["layer_ms_per_step"] = sum(step_ms) / len(step_ms)
         api["bitwise_equal_to_c_entry"] = bool(torch.equal(loop.value, out))
         loop.value = None
+        del out, work, direct
+        torch.cuda.empty_cache()
         deg = torch.empty(g.n_rows, dtype=torch.float32, device=device)
         nat.check(lib.gnx_graph_colsum(g.handle, 0.0, 0, 0, nat.ptr(deg), nat.current_stream()))
         E0 = deg.sqrt()[:, None] * (1.0 + torch.arange(C, dtype=torch.float32, device=device) / C)[None, :]
@@ -641,6 +644,7 @@ def main():
     if world > 1 and not args.no_alt_grid and not args.grid and C % world == 0:
         note("second field: the whole graph on every rank, C / N columns each")
         kernel_blocks = sg.graph.last_kernel()
+        graphs.clear()
         del state, sg, H0
         torch.cuda.empty_cache()
         from gnntf import _native as nat
@@ -707,7 +711,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         if not sharded_path and not args.no_secondary:
-            del g, adj, H0, out, work, model, loop
+            del g, adj, H0, model, loop
             torch.cuda.empty_cache()
             note("secondary workloads")
             result["secondary"] = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4")

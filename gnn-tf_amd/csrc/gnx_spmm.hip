@@ -710,20 +710,21 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float *__restrict__ X
 
 // The HBM yardsticks bench.py measures beside the SpMM (gnx_stream_copy / gnx_stream_read): every block walks tiles of
 // blockDim.x * U float4, U independent 16-byte non-temporal loads in flight per lane (each wave instruction moves 1 KiB of
-// consecutive bytes), non-temporal stores.  Launch shape from tools/stream_bench.hip's sweep on this box.
-constexpr int STREAM_U = 8, STREAM_THREADS = 512, STREAM_BLOCKS = 256 * 4;
-template <bool COPY>
-__global__ __launch_bounds__(STREAM_THREADS) void k_stream(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4,
-                                                           float *__restrict__ sink) {
-    const int64_t tile = (int64_t)blockDim.x * STREAM_U;
+// consecutive bytes), non-temporal stores.  Launch shapes from tools/stream_bench.hip's sweep on an MI355X
+// (profiles/r03_stream_sweep.txt): a copy is fastest with many waves (1024 threads x 4 blocks per CU, 4 loads in flight:
+// 5.8 TB/s read + write), a read with FEW (one 256-thread block per CU, 8 loads in flight: 7.2 TB/s) -- more waves only
+// spread the DRAM pages thinner.
+template <int U, bool COPY>
+__global__ void k_stream(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int64_t n4, float *__restrict__ sink) {
+    const int64_t tile = (int64_t)blockDim.x * U;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     int64_t base = (int64_t)blockIdx.x * tile;
     for (; base + tile <= n4; base += (int64_t)gridDim.x * tile) {
-        f32x4 v[STREAM_U];
+        f32x4 v[U];
 #pragma unroll
-        for (int u = 0; u < STREAM_U; ++u) v[u] = __builtin_nontemporal_load(src + base + (int64_t)u * blockDim.x + threadIdx.x);
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(src + base + (int64_t)u * blockDim.x + threadIdx.x);
 #pragma unroll
-        for (int u = 0; u < STREAM_U; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (COPY) __builtin_nontemporal_store(v[u], dst + base + (int64_t)u * blockDim.x + threadIdx.x);
             else acc += v[u];
         }
@@ -1216,7 +1217,7 @@ int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *st
     GNX_CHECK_ARG(n_floats >= 0 && n_floats % 4 == 0, "gnx_stream_copy: the length must be a multiple of 4 floats");
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_dst && aligned(d_src, 16) && aligned(d_dst, 16), "gnx_stream_copy: NULL or unaligned pointer");
-    hipLaunchKernelGGL(k_stream<true>, dim3(STREAM_BLOCKS), dim3(STREAM_THREADS), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst,
+    hipLaunchKernelGGL((k_stream<4, true>), dim3(256 * 4), dim3(1024), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)d_dst,
                        n_floats / 4, (float *)nullptr);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
@@ -1244,7 +1245,7 @@ int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void 
     GNX_CHECK_ARG(n_floats >= 0 && n_floats % 4 == 0, "gnx_stream_read: the length must be a multiple of 4 floats");
     if (n_floats == 0) return GNX_OK;
     GNX_CHECK_ARG(d_src && d_sink64 && aligned(d_src, 16), "gnx_stream_read: NULL or unaligned pointer");
-    hipLaunchKernelGGL(k_stream<false>, dim3(STREAM_BLOCKS), dim3(STREAM_THREADS), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)nullptr,
+    hipLaunchKernelGGL((k_stream<8, false>), dim3(256), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)d_src, (f32x4 *)nullptr,
                        n_floats / 4, d_sink64);
     GNX_HIP(hipGetLastError());
     return GNX_OK;

@@ -170,8 +170,8 @@ def test_vertex_blocks_of_one_graph_match_one_gpu(gnntf, world, cover, n, entrie
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "vertex_block_errors.json"), "a") as f:
         f.write(json.dumps(dict(world=world, cover=cover, n=n, C=C, max_err_over_row_max=err, max_err_over_sum_of_abs_terms=rel)) + "\n")
-    assert rel < (8 if cover == "pull" else 32) * 1.2e-7, (rel, err)     # a few float32 roundings of the element's own sum
-    assert err < (2e-6 if cover == "pull" else 2e-5), err
+    assert rel < 8 * 1.2e-7, (rel, err)     # a few float32 roundings of the element's own sum (measured: 1.4e-7 ... 1.8e-7, pull and cover alike)
+    assert err < 2e-6, err                  # (measured 2.8e-7 ... 4.2e-7 of the row maximum; round 2 accepted 2e-4)
     assert (got.argmax(1) == want.argmax(1)).float().mean().item() > 0.9999
 
 

@@ -856,7 +856,7 @@ def test_chained_training_forward_equals_step_loop(gnntf, C):
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
 
 
-@pytest.mark.parametrize("n", [4, 4 * 512 * 8 * 3, 4 * (512 * 8 * 1024 * 2 + 12345), 4 * 999_983])
+@pytest.mark.parametrize("n", [4, 4 * 1024 * 4 * 3, 4 * (1024 * 4 * 1024 * 2 + 12345), 4 * 999_983])
 def test_stream_yardsticks_move_every_element(gnntf, n):
     """gnx_stream_copy / gnx_stream_read (bench.py's measured-peak yardsticks): whole tiles, ragged tails and lengths below one tile."""
     from gnntf import _native as nat

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Rehearsal of `bench.py --gpus N` on ONE card: N ranks share cuda:0 and exchange over gloo (staged through the host), on a
+# reduced graph.  Exercises everything the driver's multi-GPU run does except RCCL itself: launcher environment, plan building
+# for both halo plans, the variant table, the timed region, the self check through the exchange, the JSON line.
+# A GPU box admits at most 6 processes on its card and the launcher is one of them, so N <= 5 here; all 8 blocks of one graph run as threads of one process
+# in tests/test_gpu_fullsize.py (same plan, same kernels, exchange through shared memory).
+#   tools/rehearse_bench.sh OUTDIR [N ...]
+set -o pipefail
+out=${1:-gpurun_out}; shift
+ranks=${@:-2 4 5}
+mkdir -p "$out"
+for n in $ranks; do
+  port=$((29600 + n))
+  GNX_BENCH_BACKEND=gloo timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
+      bench.py --gpus "$n" --nodes 1500000 --entries 18000000 --feats 64 --steps 2 --warmup 1 --no-alt-grid \
+      > "$out/rehearsal_gloo_n$n.json" 2> "$out/rehearsal_gloo_n$n.err" || { echo "rehearsal with $n ranks failed"; tail -5 "$out/rehearsal_gloo_n$n.err"; exit 1; }
+  echo "rehearsal $n ranks: $(python -c "import json,sys; d=json.load(open('$out/rehearsal_gloo_n$n.json')); print(d['ms_per_step'], d['config']['halo']['chosen'], d['config']['self_check']['ok'])")"
+done
