@@ -846,7 +846,15 @@ class ShardedGraph:
         self._pull(full, back)                                                   # the owners' scales into the halo columns
         return full.t().contiguous()
 
-    def propagate_dropped(self, H0, a, iterations, p, seed, first_stream, scales):
+    def _dropout_chunks(self, C, chunks):
+        """Column chunks of the edge-dropout path: every column of H propagates alike (the masks and scales belong to the entries),
+        so the exchange of one chunk runs on the exchange lane under the SpMM of the next.  Default: two chunks from 64 columns on
+        (narrower chunks would pay more for the per-entry weights, which every launch recomputes, than the overlap returns)."""
+        if self.world == 1:
+            return [(0, C)]
+        return split_columns(C, (2 if C >= 64 else 1) if chunks is None else chunks)
+
+    def propagate_dropped(self, H0, a, iterations, p, seed, first_stream, scales, chunks=None):
         """The K training-mode iterations over this rank's rows: H <- (1-a) A_k H + a H0, k = 0 .. K-1."""
         self._need_dropout_block()
         be = self.backend
@@ -862,39 +870,76 @@ class ShardedGraph:
                 be.spmm_dropped_chained(self.graph, scales[k], p, seed, first_stream + k, k > 0, nxt(k), H, H0, 1.0 - a, a, out)
                 H = out
             return H
-        bufs = [torch.zeros((self.n_buf, C), dtype=torch.float32, device=dev) for _ in range(2)]
-        send = torch.zeros((max(self.n_send, 1), C), dtype=torch.float32, device=dev)
-        self.local_view(bufs[0]).copy_(H0)
+        if iterations == 0:
+            return H0.clone()
+        cols = self._dropout_chunks(C, chunks)
+        lanes = self._lanes
+        bufs = [[torch.zeros((self.n_buf, c1 - c0), dtype=torch.float32, device=dev) for _ in range(2)] for c0, c1 in cols]
+        send = [torch.zeros((max(self.n_send, 1), c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in cols]
+        result = torch.empty_like(H0)
+        packed = []
+        for c, (c0, c1) in enumerate(cols):
+            self.local_view(bufs[c][0]).copy_(H0[:, c0:c1])
+            if self.n_send:
+                be.halo_pack(self.halo, "pull", bufs[c][0], send[c])
+            packed.append(lanes.mark())
         for k in range(iterations):
-            src, dst = bufs[k % 2], bufs[1 - k % 2]
-            self._pull(src, send)
-            be.spmm_dropped_chained(self.graph, scales[k], p, seed, first_stream + k, k > 0, nxt(k), src, H0, 1.0 - a, a,
-                                    self.local_view(dst))
-        return self.local_view(bufs[iterations % 2]).clone()
+            last = k == iterations - 1
+            for c, (c0, c1) in enumerate(cols):
+                src, dst = bufs[c][k % 2], bufs[c][1 - k % 2]
+                with lanes.exchange_lane():                            # under the other chunk's SpMM
+                    lanes.wait(packed[c], on_exchange_lane=True)
+                    self.comm.exchange([send[c][a0:a1] if a1 > a0 else None for a0, a1 in self.send_pull_slices],
+                                       [src[a0:a1] if a1 > a0 else None for a0, a1 in self.recv_slices])
+                    arrived = lanes.mark(on_exchange_lane=True)
+                lanes.wait(arrived)
+                out = result[:, c0:c1] if last else self.local_view(dst)
+                be.spmm_dropped_chained(self.graph, scales[k], p, seed, first_stream + k, k > 0, nxt(k), src, H0[:, c0:c1], 1.0 - a, a, out)
+                if not last:
+                    if self.n_send:
+                        be.halo_pack(self.halo, "pull", dst, send[c])
+                    packed[c] = lanes.mark()
+        return result
 
-    def propagate_dropped_backward(self, g, a, iterations, p, seed, first_stream, scales):
+    def propagate_dropped_backward(self, g, a, iterations, p, seed, first_stream, scales, chunks=None):
         """dH0 of propagate_dropped for the output gradient g (this rank's rows): g_k = (1-a) A_k^T g_{k+1},
-        dH0 = g_0 + a sum_k g_{k+1}.  A_k^T reaches the halo columns too: those rows go back to their owners."""
+        dH0 = g_0 + a sum_k g_{k+1}.  A_k^T reaches the halo columns too: those rows go back to their owners -- chunk by chunk,
+        the return trip of one column chunk under the transposed SpMM of the next."""
         self._need_dropout_block()
         be = self.backend
         G = g.to(torch.float32).contiguous()
         C, dev = G.shape[1], G.device
         gH0 = torch.zeros_like(G)
-        if self.world > 1:
-            full = torch.empty((self.n_buf, C), dtype=torch.float32, device=dev)
-            back = torch.zeros((max(self.n_send, 1), C), dtype=torch.float32, device=dev)
-        for k in range(iterations - 1, -1, -1):
-            gH0.add_(G, alpha=a)
-            if self.world == 1:
+        if self.world == 1:
+            for k in range(iterations - 1, -1, -1):
+                gH0.add_(G, alpha=a)
                 nxt = torch.empty_like(G)
                 be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, True, G, None, 1.0 - a, 0.0, nxt)
-            else:
-                be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, True, G, None, 1.0 - a, 0.0, full)
-                self._exchange_back(full, back)
-                nxt = torch.empty_like(G)
-                self._add_back(full, back, nxt)
-            G = nxt
-        gH0.add_(G)
+                G = nxt
+            gH0.add_(G)
+            return gH0
+        cols = self._dropout_chunks(C, chunks)
+        lanes = self._lanes
+        full = [torch.empty((self.n_buf, c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in cols]
+        back = [torch.zeros((max(self.n_send, 1), c1 - c0), dtype=torch.float32, device=dev) for c0, c1 in cols]
+        Gc = [G[:, c0:c1].contiguous() for c0, c1 in cols]
+        for k in range(iterations - 1, -1, -1):
+            returned = []
+            for c, (c0, c1) in enumerate(cols):
+                gH0[:, c0:c1].add_(Gc[c], alpha=a)
+                be.spmm_dropped(self.graph, scales[k], p, seed, first_stream + k, True, Gc[c], None, 1.0 - a, 0.0, full[c])
+                computed = lanes.mark()
+                with lanes.exchange_lane():
+                    lanes.wait(computed, on_exchange_lane=True)
+                    self._exchange_back(full[c], back[c])
+                    returned.append(lanes.mark(on_exchange_lane=True))
+            for c in range(len(cols)):
+                lanes.wait(returned[c])
+                nxt = torch.empty_like(Gc[c])
+                self._add_back(full[c], back[c], nxt)
+                Gc[c] = nxt
+        for c, (c0, c1) in enumerate(cols):
+            gH0[:, c0:c1].add_(Gc[c])
         return gH0
 
     # ---- measurements for bench.py ------------------------------------------------------------------------

@@ -383,6 +383,11 @@ def dropout_on_blocks(rank, world, dev, backend, directed):
     H0 = torch.from_numpy(H0_full[lo:hi].copy()).to(dev)
     out = sg.propagate_dropped(H0, a, K, p, seed, first, scales)
     gH0 = sg.propagate_dropped_backward(torch.from_numpy(G_full[lo:hi].copy()).to(dev), a, K, p, seed, first, scales)
+    for chunks in (2, 3):                                          # column chunks (exchange of one under the SpMM of the next): same columns, same sums
+        out_c = sg.propagate_dropped(H0, a, K, p, seed, first, scales, chunks=chunks)
+        gH0_c = sg.propagate_dropped_backward(torch.from_numpy(G_full[lo:hi].copy()).to(dev), a, K, p, seed, first, scales, chunks=chunks)
+        np.testing.assert_allclose(out_c.cpu().numpy(), out.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(gH0_c.cpu().numpy(), gH0.cpu().numpy(), rtol=1e-6, atol=1e-7)
     # ---- single process, the oracle's get_adjacency in training mode with the same (seed, stream) per iteration ---------
     adjs = [orc.get_adjacency(coo, vals, (n, n), graph_dropout=p, training=True, seed=seed, stream=first + k) for k in range(K)]
     H = H0_full.astype(np.float64)
