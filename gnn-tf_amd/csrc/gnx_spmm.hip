@@ -297,9 +297,64 @@ __device__ __forceinline__ void group_rows(const SpmmArgs &p, int64_t block) {
     }
 }
 
+// The same rows with a COOPERATIVE index fetch, for the narrow groups (G <= 8 lanes per row, C <= 32).  In group_rows every lane of a
+// row's group loads the same (col, val) pair, so a step of four entries costs four index loads + four value loads + four gathers
+// per lane: twelve vector-memory instructions, each served line by line by the CU's L1 pipe (sixteen different lines per wave
+// instruction).  At narrow widths that pipe is what a launch waits for next to the fabric (SQ counters at C = 8: 60 % of the
+// wave cycles are issue stalls, the TCP is busy for the whole launch; with every gather made to hit, a launch still takes 57 %
+// of its time -- profiles/notes/r03_narrow_*).  Here lane `sub` of the group loads the pair of entry base + sub -- ONE index
+// load and one value load per four entries -- and the group reads them out of each other's registers (ds_bpermute, off the memory
+// pipe); the next batch's pairs are fetched behind the gathers.  Entries are added in ascending order as before: same bits.
+// Measured (RMAT 10M / 100M, K = 10): C = 8 17.2 -> 16.4 ms, C = 16 19.5 -> 19.0, C = 32 22.2 -> 21.9; the all-gathers-hit floor
+// 9.8 -> 7.6 ms at C = 8.  The wider groups LOSE 2-4 % with it (their gathers dominate the pipe, the shuffles only add latency).
+template <int VEC, int G, int B>
+__device__ __forceinline__ void group_rows_coop(const SpmmArgs &p, int64_t block) {
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int64_t slot = p.slot0 + block * RPB + threadIdx.x / G;
+    if (slot >= p.n_rows) return;
+    const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
+    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    if (end - beg > p.long_row) return;
+    if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
+    for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
+        const int c = c0 + sub * VEC;
+        const bool active = c < p.C;
+        const float *__restrict__ Xc = p.X + (active ? c : 0);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        int myj = -1;
+        float myw = 0.f;
+        if (sub < B && beg + sub < end) { myj = p.colidx[beg + sub]; myw = p.vals[beg + sub]; }
+        for (int64_t e = beg; e < end; e += B) {
+            float x[B][VEC];
+            float w[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {                                   // gathers of this batch
+                const int j = __shfl(myj, u, G);
+                w[u] = __shfl(myw, u, G);
+                if (j >= 0) vload<VEC>(x[u], Xc + (int64_t)j * p.ldx);
+                else {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) x[u][v] = 0.f;
+                }
+            }
+            myj = -1; myw = 0.f;                                            // pairs of the next batch, behind the gathers
+            if (sub < B && e + B + sub < end) { myj = p.colidx[e + B + sub]; myw = p.vals[e + B + sub]; }
+#pragma unroll
+            for (int u = 0; u < B; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(w[u], x[u][v], acc[v]);
+        }
+        epilogue_store<VEC>(p, row, c, active, acc);
+    }
+}
+
 template <int VEC, int G, int U, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
-    group_rows<VEC, G, U, PIPE>(p, blockIdx.x);
+    if (G <= 8 && !(p.tune & 32768)) group_rows_coop<VEC, G, 4>(p, blockIdx.x);     // (tune bit: tuning builds' A/B switch back to the per-lane fetch)
+    else group_rows<VEC, G, U, PIPE>(p, blockIdx.x);
 }
 
 // ---- GCNII layer: SpMM + mix + C x C transform on the matrix cores + activation, one launch ------------------------
@@ -485,6 +540,7 @@ __global__ __launch_bounds__(256) void k_spmm_long_partial_group(const SpmmArgs 
 template <int VEC, int G, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group_and_chunks(const SpmmArgs p, int chunk_blocks) {
     if ((int)blockIdx.x < chunk_blocks) long_chunks_group<VEC, G, 4>(p, blockIdx.x);
+    else if (G <= 8) group_rows_coop<VEC, G, 4>(p, (int64_t)blockIdx.x - chunk_blocks);
     else group_rows<VEC, G, 4, PIPE>(p, (int64_t)blockIdx.x - chunk_blocks);
 }
 
@@ -926,6 +982,7 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
 #endif
     p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     p.partial = nullptr;
+    if (p.tune & 16384) p.ldx = 0;             // (tuning builds: every gather reads row 0 -- what a launch costs without its gather misses; wrong results)
     p.skip_empty = (p.act & GNX_ACT_SKIP_EMPTY) != 0 && p.diag == nullptr;
     p.act &= ~GNX_ACT_SKIP_EMPTY;
     if (m.n_rows == 0) return GNX_OK;

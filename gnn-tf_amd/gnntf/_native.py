@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
+# GNX_LIBRARY: another build of the same library (the tuning build of tools/, `make TUNING=1` -> lib/tune/libgnx.so)
+LIB_PATH = os.environ.get("GNX_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
 
 NORM = {"none": 0, "symmetric": 1, "bipartite": 2}
 EYE = {"none": 0, "before": 1, "after": 2}

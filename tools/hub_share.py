@@ -18,6 +18,6 @@ out = {}
 for name, c in (("all_rows", cnt), ("short_rows_only", cnt_short)):
     s, _ = torch.sort(c, descending=True)
     cs = torch.cumsum(s, 0).double() / s.sum().double()
-    out[name] = {str(k): round(float(cs[k - 1]), 4) for k in (128, 1024, 4096, 32768, 262144, 1048576)}
+    out[name] = {str(k): round(float(cs[k - 1]), 4) for k in (128, 1024, 4096, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152)}
     out[name]["max_refs"] = int(s[0])
 print(json.dumps(out, indent=1))
