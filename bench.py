@@ -358,17 +358,31 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     torch.cuda.empty_cache()
     # the matrix-core ends of the path at the config-4 size
     mf = {}
-    C = 64
-    H, H0 = torch.rand(n, C, device=device) * 2 - 1, torch.rand(n, C, device=device) * 2 - 1
-    M = 0.6 * torch.eye(C, device=device) + 0.4 * torch.randn(C, C, device=device) / 8
-    with torch.no_grad():
-        t_fused = median_ms(lambda: gnntf.gcnii_step(adj, H, H0, a, M, relu=True), reps=5, warm=2)
-        kernel = g.last_kernel()
-        t_two = median_ms(lambda: gnntf.dense(gnntf.ppr_step(adj, H, H0, a), M, None, relu=True), reps=5, warm=2)
-    mf["gcnii_layer_C64"] = {"fused_ms": t_fused, "spmm_then_dense_ms": t_two, "kernel": kernel,
-                             "what": "relu(((1-a) A.H + a H0) . M) on the config-4 graph: one launch (mixed rows stay in LDS, MFMA epilogue) vs "
-                                     "fused SpMM+mix followed by gnx_dense"}
-    del H, H0
+    for C in (64, 128):
+        H, H0 = torch.rand(n, C, device=device) * 2 - 1, torch.rand(n, C, device=device) * 2 - 1
+        M = 0.6 * torch.eye(C, device=device) + 0.4 * torch.randn(C, C, device=device) / 8
+        with torch.no_grad():
+            t_fused = median_ms(lambda: gnntf.gcnii_step(adj, H, H0, a, M, relu=True), reps=5, warm=2)
+            kernel = g.last_kernel()
+            t_two = median_ms(lambda: gnntf.dense(gnntf.ppr_step(adj, H, H0, a), M, None, relu=True), reps=5, warm=2)
+        # training: forward + backward of the layer (dM, dH, dH0); the fused launch also writes the mixed rows it would otherwise re-read
+        Ht, H0t, Mt = H.clone().requires_grad_(), H0.clone().requires_grad_(), M.clone().requires_grad_()
+        up = torch.rand(n, C, device=device)
+
+        def train(fused):
+            for t in (Ht, H0t, Mt):
+                t.grad = None
+            out = gnntf.gcnii_step(adj, Ht, H0t, a, Mt, relu=True) if fused else gnntf.dense(gnntf.ppr_step(adj, Ht, H0t, a), Mt, None, relu=True)
+            out.backward(up)
+        t_train = median_ms(lambda: train(True), reps=3, warm=1)
+        t_train_two = median_ms(lambda: train(False), reps=3, warm=1)
+        mf[f"gcnii_layer_C{C}"] = {"fused_ms": t_fused, "spmm_then_dense_ms": t_two, "kernel": kernel,
+                                   "train_fwd_bwd_fused_ms": t_train, "train_fwd_bwd_two_launch_ms": t_train_two,
+                                   "what": "relu(((1-a) A.H + a H0) . M) on the config-4 graph: one launch (mixed rows stay in LDS, MFMA epilogue) vs "
+                                           "fused SpMM+mix followed by gnx_dense; train_*: forward + backward of the layer, the fused launch writing "
+                                           "the mixed rows the backward needs"}
+        del H, H0, Ht, H0t, Mt, up, M
+        torch.cuda.empty_cache()
     X = torch.randn(n, 256, device=device)
     W, b = torch.randn(256, 64, device=device) / 16, torch.randn(1, 64, device=device)
     with torch.no_grad():

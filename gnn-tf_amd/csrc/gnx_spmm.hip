@@ -360,11 +360,15 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
 // ---- GCNII layer: SpMM + mix + C x C transform on the matrix cores + activation, one launch ------------------------
 //   out[i,:] = act( (beta * sum_j A[i,j] X[j,:] + alpha * H0[i,:]) . M ),   M = (1-b) I + b W   (gcn.py:22-27)
 // A 512-thread block: every wave gathers a tile of 16 rows (4 NT lanes of float4 per row, U entries in flight per lane,
-// rows in degree-binned order), leaves the mixed rows in its LDS tile -- they never go to HBM -- multiplies the tile by
-// M (shared by the block in LDS, row stride = 4 mod 32 banks) with v_mfma_f32_16x16x4_f32 (exact f32), and stores whole
-// rows.  C = 16 NT for NT in {1, 2, 4}; rows longer than p.long_row are left to the long-row kernels + the dense kernel.
+// rows in degree-binned order), leaves the mixed rows in its LDS tile -- in inference they never go to HBM; in training
+// (`mixed` given) each lane also stores its piece of the mixed row, which the backward needs for dM = T^T g, so that the row is
+// written once and NOT read back for the transform -- multiplies the tile by M (shared by the block in LDS, row stride = 4 mod 32
+// banks) with v_mfma_f32_16x16x4_f32 (exact f32), and stores whole rows.  C = 16 NT for NT in {1, 2, 4}.  (NT = 8, C = 128, fits --
+// 135 KB of the CU's 160 KB of LDS -- but leaves one block of eight waves per CU: measured 19.2 ms against 11.8 ms for SpMM+mix
+// followed by the dense kernel, so wide layers keep the two launches.)  Rows longer than p.long_row are left to the long-row
+// kernels + the dense kernel.
 template <int NT, int U, int WPB>
-__global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const float *__restrict__ M, int64_t ldm) {
+__global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const float *__restrict__ M, int64_t ldm, float *__restrict__ mixed) {
     constexpr int C = 16 * NT, G = 4 * NT, RPP = 64 / G, PASSES = 16 / RPP, STRIDE = C + 4;
     __shared__ float Ms[C * STRIDE];
     __shared__ float Ts[WPB][16 * STRIDE];
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const
             vload<4>(h0, p.H0 + row * p.ldh0 + c);
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[v] = fmaf(acc[v], p.beta, h0[v] * p.alpha);      // filter.py:20-21 / gcn.py:25
+            if (mixed) vstore<4>(mixed + row * (int64_t)C + c, acc);
         }
         vstore<4>(T + rr * STRIDE + c, acc);
     }
@@ -1165,7 +1170,7 @@ int gnx_spmm_tv(gnx_graph_t g, const float *d_vals_t, const float *d_diag, const
 }
 
 int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const float *d_H0, float a, int64_t C, const float *d_M,
-                   int64_t ldm, int act, float *d_out, float *d_work, void *stream) {
+                   int64_t ldm, int act, float *d_out, float *d_mixed, void *stream) {
     int rc = check_common("gnx_gcnii_step", g, d_H, C, C, d_H0, C, d_out, C);
     if (rc != GNX_OK) return rc;
     GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_gcnii_step: invalid activation %d", act);
@@ -1174,13 +1179,16 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
     hipStream_t s = (hipStream_t)stream;
     const Csr &m = g->a;
     const float beta = (float)(1.0 - (double)a);
-    const bool fusable = (C == 16 || C == 32 || C == 64) && aligned(d_H, 16) && aligned(d_H0, 16) && aligned(d_out, 16);
-    if (!fusable) {   // wide or odd widths: the fused SpMM+mix into the scratch, then the transform on the matrix cores
-        GNX_CHECK_ARG(d_work != nullptr && d_work != d_out && d_work != d_H, "gnx_gcnii_step: width %lld needs a distinct d_work [n, C]", (long long)C);
-        rc = gnx_spmm(g, d_vals, nullptr, d_H, C, C, d_H0, C, beta, a, GNX_ACT_NONE, d_work, C, stream);
+    GNX_CHECK_ARG(d_mixed == nullptr || (d_mixed != d_out && d_mixed != d_H && d_mixed != d_H0), "gnx_gcnii_step: d_mixed must be a buffer of its own");
+    // C = 128 fits the kernel (135 KB of LDS: one block of eight waves per CU) and was measured: 19.2 ms against 11.8 ms for the two
+    // launches on the config-4 graph -- eight waves per CU cannot keep the gathers fed -- so it takes the two-launch form
+    const bool fusable = (C == 16 || C == 32 || C == 64) && aligned(d_H, 16) && aligned(d_H0, 16) && aligned(d_out, 16) && aligned(d_mixed, 16);
+    if (!fusable) {   // other widths: the fused SpMM+mix into d_mixed, then the transform on the matrix cores
+        GNX_CHECK_ARG(d_mixed != nullptr, "gnx_gcnii_step: width %lld needs d_mixed [n, C] (the mixed rows go through memory)", (long long)C);
+        rc = gnx_spmm(g, d_vals, nullptr, d_H, C, C, d_H0, C, beta, a, GNX_ACT_NONE, d_mixed, C, stream);
         if (rc != GNX_OK) return rc;
         g->last_kernel = "spmm+dense_mfma";
-        return dense_rows(d_work, C, m.n_rows, C, d_M, ldm, C, nullptr, act, nullptr, nullptr, d_out, C, s);
+        return dense_rows(d_mixed, C, m.n_rows, C, d_M, ldm, C, nullptr, act, nullptr, nullptr, d_out, C, s);
     }
     if (m.n_rows == 0) return GNX_OK;
     SpmmArgs p{};
@@ -1190,17 +1198,19 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
     p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     const unsigned grid = blocks_for(blocks_for(m.n_rows, 16), 8);
-    if (C == 64)      hipLaunchKernelGGL((k_spmm_gcnii<4, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
-    else if (C == 32) hipLaunchKernelGGL((k_spmm_gcnii<2, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
-    else              hipLaunchKernelGGL((k_spmm_gcnii<1, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm);
+    if (C == 64)      hipLaunchKernelGGL((k_spmm_gcnii<4, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm, d_mixed);
+    else if (C == 32) hipLaunchKernelGGL((k_spmm_gcnii<2, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm, d_mixed);
+    else              hipLaunchKernelGGL((k_spmm_gcnii<1, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm, d_mixed);
     g->last_kernel = "spmm_gcnii_mfma";
-    if (m.n_long > 0) {   // hub rows: chunked partial sums -> mixed rows written in place -> transform of those rows alone
+    if (m.n_long > 0) {   // hub rows: chunked partial sums -> mixed rows (into d_mixed when kept, else in place) -> transform of those rows alone
         rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float));
         if (rc != GNX_OK) return rc;
         p.partial = g->partial;
         p.act = GNX_ACT_NONE;
+        float *rows_at = d_mixed ? d_mixed : d_out;
+        p.out = rows_at;
         launch_long<4>(p, s);
-        rc = dense_rows(d_out, C, m.n_long, C, d_M, ldm, C, nullptr, act, m.long_rows, m.long_rows, d_out, C, s);
+        rc = dense_rows(rows_at, C, m.n_long, C, d_M, ldm, C, nullptr, act, m.long_rows, m.long_rows, d_out, C, s);
         if (rc != GNX_OK) return rc;
     }
     GNX_HIP(hipGetLastError());

@@ -233,9 +233,9 @@ class GCN(GNN):
 
 class GCNIILayer(Layer):
     """gcn.py:7-27: dropout(act(((1-a) A.H + a H0) . ((1-b) I + b W))), b = beta_transformer(l / (k+1)).
-    Inference: ONE launch per layer for C in {16, 32, 64} -- the mixed rows stay in LDS and meet (1-b) I + b W on the
-    matrix cores before the only store (gnx_gcnii_step); training keeps the mixed rows (dW needs them) and runs the
-    transform as its own matrix-core launch."""
+    ONE launch per layer for C in {16, 32, 64} -- the mixed rows stay in LDS and meet (1-b) I + b W on the matrix cores
+    (gnx_gcnii_step); in training the same launch also writes the mixed rows once (dW needs them) instead of a second launch
+    reading them back."""
 
     def __build__(self, architecture, H0: Layer, a: float, l: float, k: int = 0, activation=linear,
                   beta_transformer=math.log1p, dropout: float = 0.5, graph_dropout: float = 0.5, regularization=True):

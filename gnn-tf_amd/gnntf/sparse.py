@@ -599,12 +599,8 @@ def dense(X: torch.Tensor, W: torch.Tensor, bias=None, relu=False) -> torch.Tens
     return _DenseAct.apply(X, W, bias, bool(relu))
 
 
-def gcnii_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a: float, M: torch.Tensor, relu=True) -> torch.Tensor:
-    """act(((A . H)(1-a) + H0 a) . M), M = (1-b) I + b W (gcn.py:22-27).  Without autograd (inference) this is ONE fused
-    launch -- the mixed rows never reach HBM (gnx_gcnii_step); when gradients are needed the mixed rows must exist for
-    dM = T^T g, so the step runs as the fused SpMM+mix followed by the matrix-core transform."""
-    if torch.is_grad_enabled() and (H.requires_grad or H0.requires_grad or M.requires_grad):
-        return dense(ppr_step(adj, H, H0, a), M, None, relu)
+def _gcnii_launch(adj: Adjacency, H, H0, a, M, relu, keep_mixed):
+    """gnx_gcnii_step; returns (out, T or None).  T = the mixed rows (A.H)(1-a) + H0 a, written by the same launch when kept."""
     g = adj.graph
     nat.require_cuda(H, H0, M)
     H, H0, M = _as_f32_rows(H).contiguous(), _as_f32_rows(H0).contiguous(), _as_f32_rows(M)
@@ -614,11 +610,49 @@ def gcnii_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a: float, M: t
     if adj.diag is not None:
         raise Exception("gcnii_step: add_eye adjacencies are not supported by the fused step")
     out = torch.empty_like(H)
-    work = None if C in (16, 32, 64) else torch.empty_like(H)
+    mixed = torch.empty_like(H) if keep_mixed or C not in (16, 32, 64) else None
     with nat.on_device(H.device):
         nat.check(nat.lib().gnx_gcnii_step(g.handle, nat.ptr(adj.vals), nat.ptr(H), nat.ptr(H0), float(a), C, nat.ptr(M), M.stride(0),
-                                           nat.ACT_RELU if relu else nat.ACT_NONE, nat.ptr(out), nat.ptr(work), nat.current_stream()))
-    return out
+                                           nat.ACT_RELU if relu else nat.ACT_NONE, nat.ptr(out), nat.ptr(mixed), nat.current_stream()))
+    return out, mixed
+
+
+class _GCNIIStep(torch.autograd.Function):
+    """out = act(T . M), T = (A . H)(1-a) + H0 a, as ONE launch that also leaves T in memory for the backward (gcn.py:22-27 under
+    tf.GradientTape): with g' = g * (out > 0):  dM = T^T g' (gnx_dense_wgrad), dT = g' M^T (gnx_dense), dH = (1-a) A^T dT, dH0 = a dT."""
+
+    @staticmethod
+    def forward(ctx, H, H0, M, adj, a, relu):
+        out, T = _gcnii_launch(adj, H, H0, a, M, relu, keep_mixed=True)
+        ctx.adj, ctx.a, ctx.relu = adj, a, relu
+        ctx.save_for_backward(T, M, out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        T, M, out = ctx.saved_tensors
+        g = ((g * (out > 0)) if ctx.relu else g).contiguous()
+        gM = _dense_wgrad(T, g) if ctx.needs_input_grad[2] else None
+        gH = gH0 = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gT = _dense_launch(g, M.t().contiguous(), None, False)
+            if ctx.needs_input_grad[0]:
+                gH = _launch(ctx.adj, gT, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
+            if ctx.needs_input_grad[1]:
+                gH0 = gT * ctx.a
+        return gH, gH0, gM, None, None, None
+
+
+def gcnii_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a: float, M: torch.Tensor, relu=True) -> torch.Tensor:
+    """act(((A . H)(1-a) + H0 a) . M), M = (1-b) I + b W (gcn.py:22-27) -- ONE fused launch for C in {16, 32, 64}: the mixed
+    rows stay in LDS and meet M on the matrix cores (gnx_gcnii_step).  Without autograd they never reach HBM; when gradients are
+    needed the same launch also writes them (dM = T^T g needs them), once, and the transform does not read them back.  Other
+    widths run the fused SpMM+mix and then the matrix-core transform."""
+    if torch.is_grad_enabled() and (H.requires_grad or H0.requires_grad or M.requires_grad):
+        if isinstance(adj, DroppedAdjacency):                       # weights made inside the SpMM: the generic composition knows how
+            return dense(ppr_step(adj, H, H0, a), M, None, relu)
+        return _GCNIIStep.apply(H, H0, M, adj, float(a), bool(relu))
+    return _gcnii_launch(adj, H, H0, a, M, relu, keep_mixed=False)[0]
 
 
 class DeviceIndex:

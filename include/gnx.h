@@ -226,11 +226,13 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
 /* One GCNIILayer.__forward__ (gnntf/core/gnn/architectures/gcn.py:22-27) with a fixed adjacency:
  *   out = act( ((A_hat . H)*(1-a) + H0*a) . M ),   M = (1-b) I + b W  given by the caller as a [C, C] matrix (ldm).
  * For C in {16, 32, 64} (16-byte aligned buffers) this is ONE launch for all rows of at most 512 entries: the mixed rows
- * stay in LDS and meet M on the matrix cores (v_mfma_f32_16x16x4_f32, exact float32) before the only store; hub rows go
- * through the long-row kernels and the dense kernel.  Other widths run gnx_spmm into d_work [n, C] (must be given,
- * distinct from d_out and d_H) and then gnx_dense.  All matrices contiguous [n, C]; square graph. */
+ * T = (A_hat . H)*(1-a) + H0*a stay in LDS and meet M on the matrix cores (v_mfma_f32_16x16x4_f32, exact float32) before the only
+ * store; hub rows go through the long-row kernels and the dense kernel.
+ * d_mixed [n, C]: NULL in inference (T never reaches HBM).  In training pass a buffer: the same launch also writes T there -- what
+ * tf.GradientTape keeps for dM = T^T g (trainable.py:70-78) -- so T is written once and not read back for the transform.
+ * Other widths NEED d_mixed: they run gnx_spmm into it and then gnx_dense.  All matrices contiguous [n, C]; square graph. */
 int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const float *d_H0, float a, int64_t C,
-                   const float *d_M, int64_t ldm, int act, float *d_out, float *d_work, void *stream);
+                   const float *d_M, int64_t ldm, int act, float *d_out, float *d_mixed, void *stream);
 
 /* ---- the dense ends of the path (matrix cores) -----------------------------------------------------------------------
  * gnx_dense: out = act(X . W + bias) -- Dense.__forward__ (gnntf/core/nn/layers.py:135-136) and the transform of

@@ -2,6 +2,7 @@
 Dense (layers.py:135-136), the GCNII layer (gcn.py:22-27), the NodeClassification head (graph_predictor.py:16-31) and the
 sparse-input form of the first Dense.  float32 tolerance of BASELINE.json: rtol 1e-4 (+ atol for sums that cancel)."""
 import numpy as np
+import scipy.sparse as sp
 import pytest
 import torch
 
@@ -116,15 +117,28 @@ def test_gcnii_step_fused(gnntf, C, relu):
     want = np.maximum(want, 0) if relu else want
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4)
     assert g.last_kernel() == ("spmm_gcnii_mfma" if C in (16, 32, 64) else "spmm+dense_mfma")
-    # with gradients the mixed rows are kept: same values through the two-launch form, and dM / dH / dH0 flow
+    # with gradients the SAME launch also writes the mixed rows (dM needs them): bitwise the inference output, and dM / dH / dH0
+    # against float64 algebra (g = a random upstream gradient, not all ones: the hub rows' products must be right too)
     Ht, H0t, Mt = dev(H).requires_grad_(), dev(H0).requires_grad_(), dev(M).requires_grad_()
     out = gnntf.gcnii_step(adj, Ht, H0t, 0.1, Mt, relu=relu)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=RTOL, atol=1e-4)
-    out.sum().backward()
+    assert g.last_kernel() == ("spmm_gcnii_mfma" if C in (16, 32, 64) else "spmm+dense_mfma")
+    assert np.array_equal(out.detach().cpu().numpy(), got)
+    up = rng.standard_normal((n, C))
+    out.backward(dev(up.astype(np.float32)))
     T = orc.ppr_iteration(ai, av, shape, H.astype(np.float64), H0.astype(np.float64), 0.1)
-    gate = (T @ M > 0) if relu else np.ones((n, C), dtype=bool)
-    np.testing.assert_allclose(Mt.grad.cpu().numpy(), T.T @ gate, rtol=1e-3, atol=1e-2)
-    np.testing.assert_allclose(H0t.grad.cpu().numpy(), 0.1 * (gate @ M.T.astype(np.float64)), rtol=1e-3, atol=1e-4)
+    gate = ((T @ M > 0) if relu else np.ones((n, C), dtype=bool)) * up.astype(np.float32).astype(np.float64)
+    dT = gate @ M.T.astype(np.float64)
+    A = sp.csr_matrix((av, (ai[:, 0], ai[:, 1])), shape=shape)
+    np.testing.assert_allclose(Mt.grad.cpu().numpy(), T.T @ gate, rtol=1e-3, atol=2e-2)
+    np.testing.assert_allclose(H0t.grad.cpu().numpy(), 0.1 * dT, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(Ht.grad.cpu().numpy(), 0.9 * (A.T @ dT), rtol=1e-3, atol=1e-3)
+    # ... and the same gradients as the two-launch composition (fused SpMM+mix, then the dense kernel) that the step replaces
+    H2, H02, M2 = dev(H).requires_grad_(), dev(H0).requires_grad_(), dev(M).requires_grad_()
+    two = gnntf.dense(gnntf.ppr_step(adj, H2, H02, 0.1), M2, None, relu=relu)
+    two.backward(dev(up.astype(np.float32)))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), two.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for a_, b_ in ((Mt.grad, M2.grad), (Ht.grad, H2.grad), (H0t.grad, H02.grad)):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
 def test_node_head(gnntf):
