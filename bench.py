@@ -573,7 +573,19 @@ def main():
                 earlies = [False, True] if (args.early_pull == "auto" and cand.n_send_push_max > 0 and cand.n_send_pull_max > 0) \
                     else [args.early_pull == "on"]
                 for chunks in chunk_options:
-                    state = cand.make_state(H0, chunks=chunks)
+                    # a variant that cannot be set up on SOME rank (memory) is dropped on EVERY rank: the decision is collective
+                    state, problem = None, ""
+                    try:
+                        state = cand.make_state(H0, chunks=chunks)
+                    except Exception as error:
+                        problem = repr(error)[:200]
+                    ok = torch.tensor([0 if problem else 1], device=device, dtype=torch.int32)
+                    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                    if int(ok.item()) == 0:
+                        variants.append(dict(cover=cover, chunks=chunks, early_pull=None, step_ms=None, error=problem or "setup failed on another rank"))
+                        state = None
+                        torch.cuda.empty_cache()
+                        continue
                     alone = dict(exchange_ms_alone=cand.time_exchange(state, repeats=2) * 1e3, compute_ms_alone=cand.time_compute(state, a, repeats=2) * 1e3)
                     for early in earlies:
                         run = lambda: cand.propagate(state, a, K, early_pull=early)
@@ -582,7 +594,10 @@ def main():
                         note(f"variant {variants[-1]}")
                     del state
                     torch.cuda.empty_cache()
-            best = min(variants, key=lambda v: v["step_ms"])                     # the same numbers on every rank: the same choice
+            timed = [v for v in variants if v["step_ms"] is not None]
+            if not timed:
+                raise SystemExit("bench.py: no halo variant could be set up")
+            best = min(timed, key=lambda v: v["step_ms"])                        # the same numbers on every rank: the same choice
         else:
             best = dict(cover=covers[0], chunks=chunk_options[-1] if args.chunks <= 0 else args.chunks, early_pull=args.early_pull == "on")
         sg = graphs[best["cover"]]

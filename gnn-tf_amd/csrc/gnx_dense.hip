@@ -14,6 +14,9 @@
 // Tried and dropped (round 2): a persistent W-resident variant (W once in LDS, the whole K extent of a 16-row tile in
 // registers, next tile prefetched, no barrier in the loop) -- 5.1 ms vs 4.2 ms at 10M x 256 -> 64: with two waves per SIMD the
 // 64-byte-per-row A loads no longer hide (a 256 -> 7 product ran at 3.2 TB/s); the chunked kernel's eight blocks per CU do.
+#include <stdlib.h>
+#include <algorithm>
+
 #include "gnx_internal.h"
 
 using namespace gnx;
@@ -120,6 +123,147 @@ __global__ __launch_bounds__(64 * DENSE_WAVES) void k_dense_mfma(const DenseArgs
             p.out[orow * p.ldo + col] = v;
         }
     }
+}
+
+// ---- the same product with X through LDS in full lines (LDS-DMA ring), W resident in LDS --------------------------------------
+// k_dense_mfma loads the A operand "fragment-shaped": one wave instruction fetches 64 bytes of each of 16 rows, so every 128-byte
+// line of X is touched twice and the CU's L1 pipe does twice the line work of a row-contiguous read; its 32 A registers per lane
+// also cap the occupancy.  Here every wave owns 16-row tiles and streams their K chunks (64 floats = two whole lines per row)
+// into a private RING of LDS stages by LDS-DMA (global_load_lds_dwordx4: no VGPR destination, four 1-KiB wave instructions per
+// stage, each writing four rows), keeps RING - 1 stages in flight behind a counted s_waitcnt vmcnt, and reads the A fragments
+// back with ds_read_b128.  The LDS image is lane-linear (an LDS-DMA cannot pad or scatter), so the 16-byte pieces of a row are
+// XOR-swizzled by the row index on the SOURCE address; the fragment reads of a wave are then conflict-free.  W ([F, O], at most
+// 64 KB) is laid out once per block as [k][column group][c][4] so that a lane's four accumulator columns are ONE ds_read_b128,
+// again conflict-free (row stride = a multiple of the 256-byte bank row).  The block is persistent (one per CU, WAVES waves, no
+// barrier inside the loop: a wave only ever reads what it staged itself), walks tiles of 16 rows, and adds the k terms in the same
+// order as k_dense_mfma: same bits.
+constexpr int RING_BK = 64;            // floats of one row per stage
+
+template <int NT, int WAVES, int RING>
+__global__ __launch_bounds__(64 * WAVES) void k_dense_ring(const DenseArgs p, int64_t n_tiles) {
+    static_assert(NT % 4 == 0, "the W image groups the accumulator columns in fours");
+    constexpr int NQ = NT / 4;                                    // column groups of 4 x 16 outputs
+    constexpr int STAGE = 16 * RING_BK;                           // floats per stage: 16 rows x 64
+    extern __shared__ float lds[];                                // ONE array: [W image: F * NT * 16 floats][WAVES][RING][STAGE]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int w_floats = p.F * NT * 16;
+    float *__restrict__ Wl = lds;
+    float *__restrict__ ring = lds + w_floats + wave * (RING * STAGE);
+    // W image: Wl[(k * NQ + q) * 64 + cc * 4 + j] = W[k][16 (4 q + j) + cc]
+    for (int idx = threadIdx.x; idx < p.F * NT * 16; idx += 64 * WAVES) {
+        const int k = idx / (NT * 16), col = idx % (NT * 16);      // col = 16 nt + cc: coalesced reads of W's row
+        const int nt = col >> 4, cc = col & 15;
+        Wl[(k * NQ + (nt >> 2)) * 64 + cc * 4 + (nt & 3)] = col < p.O ? p.W[(int64_t)k * p.ldw + col] : 0.f;
+    }
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = (p.bias && 16 * nt + c < p.O) ? p.bias[16 * nt + c] : 0.f;
+    __syncthreads();                                              // the only barrier: W is in place
+
+    const int kchunks = p.F / RING_BK;
+    const int64_t tile_stride = (int64_t)gridDim.x * WAVES;
+    const int64_t first = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t my_tiles = first < n_tiles ? (n_tiles - first + tile_stride - 1) / tile_stride : 0;
+    const int64_t steps = my_tiles * kchunks;                     // (tile, K chunk) pairs, walked in order
+
+    // stage `step`: four LDS-DMA instructions, lane l -> row 4 i + l / 16, 16-byte slot l % 16 of that row, filled with piece slot ^ row
+    auto issue = [&](int64_t step) {
+        const int64_t tile = first + (step / kchunks) * tile_stride;
+        const int kc = (int)(step % kchunks);
+        float *dst = ring + (step % RING) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * i + (lane >> 4);
+            int64_t row = tile * 16 + r;
+            row = row < p.n ? row : p.n - 1;                      // rows past the end read a valid row and are not stored
+            const float *src = p.X + row * p.ldx + kc * RING_BK + 4 * ((lane & 15) ^ r);
+            __builtin_amdgcn_global_load_lds(src, dst + i * 256, 16, 0, 0);
+        }
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t s0 = 0; s0 < RING - 1 && s0 < steps; ++s0) issue(s0);
+    for (int64_t step = 0; step < steps; ++step) {
+        // the reads of stage step - 1 (the slot that stage step + RING - 1 overwrites) were consumed by its MFMAs: drain them, then restage
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (step + RING - 1 < steps) issue(step + RING - 1);
+        // all but the youngest 4 (RING - 1) vector-memory operations are done => stage `step` has landed (stores issued in between only
+        // make the wait stricter); near the end fewer stages are in flight behind it
+        const int64_t behind = steps - 1 - step;
+        if (behind >= RING - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING - 1)) : "memory");
+        else if (RING > 2 && behind == RING - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 2 ? RING - 2 : 0)) : "memory");
+        else if (RING > 3 && behind == RING - 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 3 ? RING - 3 : 0)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float *__restrict__ A = ring + (step % RING) * STAGE;
+        const int kc = (int)(step % kchunks);
+#pragma unroll
+        for (int T = 0; T < RING_BK / 16; ++T) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));      // X[row c][16 T + 4 g .. + 3]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kc * RING_BK + 16 * T + 4 * g + t;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Wl + (k * NQ + q) * 64 + c * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], b4[j], acc[4 * q + j], 0, 0, 0);
+                }
+            }
+        }
+        if (kc == kchunks - 1) {                                  // the tile is complete.  D layout: lane (c, g), register r -> row 4 g + r, column 16 nt + c
+            const int64_t tile = first + (step / kchunks) * tile_stride;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = 16 * nt + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = tile * 16 + 4 * g + r;
+                    float v = acc[nt][r] + bias[nt];
+                    if (p.act == GNX_ACT_RELU) v = fmaxf(v, 0.f);
+                    if (col < p.O && row < p.n) p.out[row * p.ldo + col] = v;
+                }
+                acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+// the ring kernel takes: whole float4 rows of X, F a multiple of 64, W image of at most 64 KB, accumulator columns in groups of four
+bool ring_eligible(const DenseArgs &p, bool x_aligned, int nt) {
+    return x_aligned && p.in_rows == nullptr && p.out_rows == nullptr && p.F % RING_BK == 0 && nt % 4 == 0 && (int64_t)p.F * nt * 16 * 4 <= (64 << 10) &&
+           p.n >= 16 * 1024;
+}
+
+template <int NT, int WAVES, int RING>
+int launch_ring_as(const DenseArgs &p, hipStream_t s) {
+    const size_t lds_bytes = ((size_t)p.F * NT * 16 + (size_t)WAVES * RING * 16 * RING_BK) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_ring<NT, WAVES, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+        configured = true;
+    }
+    const int64_t n_tiles = (p.n + 15) / 16;
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<int64_t>((n_tiles + WAVES - 1) / WAVES, cus);
+    hipLaunchKernelGGL((k_dense_ring<NT, WAVES, RING>), dim3(grid), dim3(64 * WAVES), lds_bytes, s, p, n_tiles);
+    return GNX_OK;
+}
+
+// Waves per block: as many 2-stage rings (8 KB each) as fit beside the W image in the CU's 160 KB of LDS, up to 16 -- measured at
+// 10M x 256 -> 64: 4 waves x 4 stages 4.14 ms, 8 x 2 3.54, 8 x 3 3.61, 12 x 2 3.41 (k_dense_mfma: 3.59); the matrix pipe wants
+// three waves per SIMD more than it wants a deeper ring.
+template <int NT>
+int launch_ring(const DenseArgs &p, hipStream_t s) {
+    const size_t w_bytes = (size_t)p.F * NT * 16 * sizeof(float);
+    const size_t rings = ((160u << 10) - w_bytes) / (2 * 16 * RING_BK * sizeof(float));
+    if (rings >= 16) return launch_ring_as<NT, 16, 2>(p, s);
+    if (rings >= 12) return launch_ring_as<NT, 12, 2>(p, s);
+    return launch_ring_as<NT, 8, 2>(p, s);
 }
 
 template <int NT>
@@ -380,6 +524,16 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p % 16) == 0; }
 namespace gnx {
 
 // used by gnx_spmm.hip (GCNII's long rows go through the dense kernel with a row scatter)
+// (tuning builds: GNX_DENSE_RING=0 keeps the register-staged kernel, for A/B runs)
+static bool ring_enabled() {
+#ifdef GNX_TUNING
+    static const bool on = [] { const char *e = getenv("GNX_DENSE_RING"); return !(e && e[0] == '0'); }();
+    return on;
+#else
+    return true;
+#endif
+}
+
 int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W, int64_t ldw, int64_t O, const float *bias, int act,
                const int32_t *in_rows, const int32_t *out_rows, float *out, int64_t ldo, hipStream_t s) {
     if (n == 0) return GNX_OK;
@@ -391,6 +545,12 @@ int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W
         q.w_aligned = ldw % 4 == 0 && aligned16(q.W);
         q.O = (int)(O - o0 < 256 ? O - o0 : 256);
         const int nt = (q.O + 15) / 16;
+        const int nt4 = nt;                                                // the ring kernel takes accumulator columns in whole groups of four
+        if (ring_enabled() && nt % 4 == 0 && ring_eligible(q, al, nt4) && nt4 <= 16) {
+            int rc = nt4 == 4 ? launch_ring<4>(q, s) : nt4 == 8 ? launch_ring<8>(q, s) : nt4 == 12 ? launch_ring<12>(q, s) : launch_ring<16>(q, s);
+            if (rc != GNX_OK) return rc;
+            continue;
+        }
         if (nt <= 1) launch_dense<1>(q, al, s);
         else if (nt <= 2) launch_dense<2>(q, al, s);
         else if (nt <= 3) launch_dense<3>(q, al, s);
