@@ -167,66 +167,69 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ring(const DenseArgs p, in
     const int64_t my_tiles = first < n_tiles ? (n_tiles - first + tile_stride - 1) / tile_stride : 0;
     const int64_t steps = my_tiles * kchunks;                     // (tile, K chunk) pairs, walked in order
 
-    // stage `step`: four LDS-DMA instructions, lane l -> row 4 i + l / 16, 16-byte slot l % 16 of that row, filled with piece slot ^ row
-    auto issue = [&](int64_t step) {
-        const int64_t tile = first + (step / kchunks) * tile_stride;
-        const int kc = (int)(step % kchunks);
-        float *dst = ring + (step % RING) * STAGE;
+    // Staging runs RING - 1 steps ahead of the arithmetic: (pf_tile, pf_kc) is the next step to stage, counted up without divisions.
+    // One stage = four LDS-DMA instructions, lane l -> row 4 i + l / 16, 16-byte slot l % 16 of that row, filled with piece slot ^ row.
+    int64_t pf_tile = first, pf_step = 0;
+    int pf_kc = 0;
+    auto issue_next = [&]() {
+        float *dst = ring + (pf_step % RING) * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * i + (lane >> 4);
-            int64_t row = tile * 16 + r;
+            int64_t row = pf_tile * 16 + r;
             row = row < p.n ? row : p.n - 1;                      // rows past the end read a valid row and are not stored
-            const float *src = p.X + row * p.ldx + kc * RING_BK + 4 * ((lane & 15) ^ r);
+            const float *src = p.X + row * p.ldx + pf_kc * RING_BK + 4 * ((lane & 15) ^ r);
             __builtin_amdgcn_global_load_lds(src, dst + i * 256, 16, 0, 0);
         }
+        ++pf_step;
+        if (++pf_kc == kchunks) { pf_kc = 0; pf_tile += tile_stride; }
     };
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int64_t s0 = 0; s0 < RING - 1 && s0 < steps; ++s0) issue(s0);
-    for (int64_t step = 0; step < steps; ++step) {
-        // the reads of stage step - 1 (the slot that stage step + RING - 1 overwrites) were consumed by its MFMAs: drain them, then restage
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (step + RING - 1 < steps) issue(step + RING - 1);
-        // all but the youngest 4 (RING - 1) vector-memory operations are done => stage `step` has landed (stores issued in between only
-        // make the wait stricter); near the end fewer stages are in flight behind it
-        const int64_t behind = steps - 1 - step;
-        if (behind >= RING - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING - 1)) : "memory");
-        else if (RING > 2 && behind == RING - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 2 ? RING - 2 : 0)) : "memory");
-        else if (RING > 3 && behind == RING - 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 3 ? RING - 3 : 0)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const float *__restrict__ A = ring + (step % RING) * STAGE;
-        const int kc = (int)(step % kchunks);
+    for (int s0 = 0; s0 < RING - 1 && s0 < steps; ++s0) issue_next();
+    int64_t step = 0;
+    for (int64_t tile = first; tile < n_tiles; tile += tile_stride) {
+        for (int kc = 0; kc < kchunks; ++kc, ++step) {
+            // the reads of stage step - 1 (the slot that stage step + RING - 1 overwrites) were consumed by its MFMAs: drain them, then restage
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (pf_step < steps) issue_next();
+            // all but the youngest 4 (RING - 1) vector-memory operations are done => stage `step` has landed (stores issued in between only
+            // make the wait stricter); near the end fewer stages are in flight behind it
+            const int64_t behind = steps - 1 - step;
+            if (behind >= RING - 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING - 1)) : "memory");
+            else if (RING > 2 && behind == RING - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 2 ? RING - 2 : 0)) : "memory");
+            else if (RING > 3 && behind == RING - 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 3 ? RING - 3 : 0)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float *__restrict__ A = ring + (step % RING) * STAGE;
 #pragma unroll
-        for (int T = 0; T < RING_BK / 16; ++T) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));      // X[row c][16 T + 4 g .. + 3]
+            for (int T = 0; T < RING_BK / 16; ++T) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));      // X[row c][16 T + 4 g .. + 3]
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int k = kc * RING_BK + 16 * T + 4 * g + t;
+                for (int t = 0; t < 4; ++t) {
+                    const int k = kc * RING_BK + 16 * T + 4 * g + t;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Wl + (k * NQ + q) * 64 + c * 4);
+                    for (int q = 0; q < NQ; ++q) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Wl + (k * NQ + q) * 64 + c * 4);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], b4[j], acc[4 * q + j], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j)
+                            acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], b4[j], acc[4 * q + j], 0, 0, 0);
+                    }
                 }
             }
         }
-        if (kc == kchunks - 1) {                                  // the tile is complete.  D layout: lane (c, g), register r -> row 4 g + r, column 16 nt + c
-            const int64_t tile = first + (step / kchunks) * tile_stride;
+        // the tile is complete.  D layout: lane (c, g), register r -> row 4 g + r, column 16 nt + c
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = 16 * nt + c;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = 16 * nt + c;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t row = tile * 16 + 4 * g + r;
-                    float v = acc[nt][r] + bias[nt];
-                    if (p.act == GNX_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (col < p.O && row < p.n) p.out[row * p.ldo + col] = v;
-                }
-                acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = tile * 16 + 4 * g + r;
+                float v = acc[nt][r] + bias[nt];
+                if (p.act == GNX_ACT_RELU) v = fmaxf(v, 0.f);
+                if (col < p.O && row < p.n) p.out[row * p.ldo + col] = v;
             }
+            acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
