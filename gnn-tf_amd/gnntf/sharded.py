@@ -24,14 +24,16 @@ Layout per rank:
     column remap of pulled rows stays MONOTONIC in the global id;
   * the main CSR over X (interior rows -- no remote column -- and boundary rows as two handles when
     ``split_rows``), values already normalised with GLOBAL column sums (gnn.py:41-42);
-  * a send CSR [rows to send x local rows]: a pulled row is a 1-entry row of weight 1, a pushed partial sum
-    a many-entry row, so ONE SpMM launch packs every outgoing message (no separate gather pass).
+  * a send buffer [rows the peers pull, peer by peer | partial sums pushed to the peers, peer by peer]: the first half is
+    a gather of local rows (short), the second the product of the PUSH graph [pushed rows x local rows] with the local
+    rows (most of the pack time); the layout and both packing launches are the library's (gnx_halo_plan_*).
 
 Each iteration and column chunk: pack -> pairwise isend/irecv (RCCL group of point-to-point transfers:
-every xGMI link carries its own peer's rows; no ring) -> fused SpMM+mix.  Overlap comes from two sources:
+every xGMI link carries its own peer's rows; no ring) -> fused SpMM+mix.  Overlap comes from three sources:
 the feature columns are cut into ``chunks`` that propagate independently (filter.py:19-21 acts on every
-column alike), so the exchange of one chunk runs on its own stream under the SpMM of the other; and the
-interior rows of a chunk are computed before its halo is waited for.
+column alike), so the exchange of one chunk runs on its own stream under the SpMM of the other; the
+interior rows of a chunk are computed before its halo is waited for; and with ``early_pull`` the pulled rows
+leave as soon as they are gathered, while the pushed partial sums are still being summed.
 
 The heavy lifting goes through a small backend object; the product backend is libgnx.so (NativeBackend).
 Tests on CPU ranks (gloo) supply their own checker backend: this module never imports a CPU implementation.
