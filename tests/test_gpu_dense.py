@@ -98,7 +98,7 @@ def hub_graph(n, m, hub_entries, seed):
     return coo, np.ones(len(coo), dtype=np.float32), shape
 
 
-@pytest.mark.parametrize("C", [16, 32, 64, 48, 128])
+@pytest.mark.parametrize("C", [16, 32, 64, 48, 128, 256])
 @pytest.mark.parametrize("relu", [True, False])
 def test_gcnii_step_fused(gnntf, C, relu):
     """gcn.py:22-27 in one launch (C = 16/32/64: LDS tile + MFMA; hub rows through the long-row + dense kernels) or as
