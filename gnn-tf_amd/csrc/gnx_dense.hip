@@ -202,18 +202,53 @@ __global__ __launch_bounds__(64 * WAVES) void k_dense_ring(const DenseArgs p, in
             else if (RING > 3 && behind == RING - 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING > 3 ? RING - 3 : 0)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const float *__restrict__ A = ring + (step % RING) * STAGE;
+            if constexpr (NQ <= 2) {
+                // the stage's A fragments up front (X[row c][16 T + 4 g .. + 3]), the B fragments one k step ahead of the MFMAs that use
+                // them: the wave hides its own LDS latency instead of waiting for every fragment it has just asked for
+                f32x4 a4[RING_BK / 16];
 #pragma unroll
-            for (int T = 0; T < RING_BK / 16; ++T) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));      // X[row c][16 T + 4 g .. + 3]
+                for (int T = 0; T < RING_BK / 16; ++T) a4[T] = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));
+                const float *__restrict__ Wk = Wl + ((kc * RING_BK + 4 * g) * NQ) * 64 + c * 4;      // fragment of k = kc 64 + 4 g (+ 16 T + t)
+                f32x4 b[2][NQ];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int k = kc * RING_BK + 16 * T + 4 * g + t;
+                for (int q = 0; q < NQ; ++q) b[0][q] = *reinterpret_cast<const f32x4 *>(Wk + q * 64);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Wl + (k * NQ + q) * 64 + c * 4);
+                for (int st = 0; st < RING_BK / 4; ++st) {                    // st = 4 T + t
+                    const int T = st >> 2, t = st & 3;
+                    if (st + 1 < RING_BK / 4) {
+                        const int T1 = (st + 1) >> 2, t1 = (st + 1) & 3;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) b[(st + 1) & 1][q] = *reinterpret_cast<const f32x4 *>(Wk + ((16 * T1 + t1) * NQ + q) * 64);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], b4[j], acc[4 * q + j], 0, 0, 0);
+                            acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[T][t], b[st & 1][q][j], acc[4 * q + j], 0, 0, 0);
+                }
+                // pin that order for the scheduler (it would otherwise sink every read next to its first use and wait for all of them):
+                // the A fragments and the first B fragment, then { next B fragment, this step's MFMAs } sixteen times
+                __builtin_amdgcn_sched_group_barrier(0x100, RING_BK / 16 + NQ, 0);
+#pragma unroll
+                for (int st = 0; st < RING_BK / 4; ++st) {
+                    if (st + 1 < RING_BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, NQ, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NQ, 0);
+                }
+            } else {
+                // wide outputs (O = 192 / 256): sixteen accumulator tiles leave no room for fragments in flight (measured: +5 % with them)
+#pragma unroll
+                for (int T = 0; T < RING_BK / 16; ++T) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int k = kc * RING_BK + 16 * T + 4 * g + t;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(Wl + (k * NQ + q) * 64 + c * 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[4 * q + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[t], b4[j], acc[4 * q + j], 0, 0, 0);
+                        }
                     }
                 }
             }
