@@ -35,3 +35,56 @@ def test_halo_exchange_over_rccl_two_gpus(tmp_path):
     for r, proc in enumerate(ranks):
         out, _ = proc.communicate(timeout=240)
         assert proc.returncode == 0 and "RCCL two-rank exchange OK" in out, (r, out[-2000:])
+
+
+NCCL_SELF = r'''
+import os, sys, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+sys.path[:0] = [sys.argv[2], os.path.join(sys.argv[2], "gnn-tf_amd")]
+from gnntf import sharded
+
+class SelfPeer(sharded.Comm):                      # a one-rank group that exchanges with itself: what the N > 1 path does per peer
+    def __init__(self):
+        self.group, self.solo, self.rank, self.size = None, False, -1, 2      # rank -1: "rank 0" is a peer like any other
+
+comm = SelfPeer()
+lanes = sharded._Lanes(dev)
+a1, a2 = torch.arange(3000., device=dev).reshape(-1, 4), -torch.arange(5000., device=dev).reshape(-1, 4)
+b1, b2 = torch.zeros_like(a1), torch.zeros_like(a2)
+# both halves of one peer's message in ONE batch (pulled rows, then pushed sums): matched in order
+comm.exchange_pairs([(0, a1), (0, a2)], [(0, b1), (0, b2)])
+torch.cuda.synchronize()
+assert torch.equal(a1, b1) and torch.equal(a2, b2), "two messages to one peer in one batch were not matched in order"
+# the same on the exchange lane behind an event, as propagate() issues it (early_pull: two batches back to back)
+c1, c2 = torch.zeros_like(a1), torch.zeros_like(a2)
+x = a1 * 2
+ready = lanes.mark()
+with lanes.exchange_lane():
+    lanes.wait(ready, on_exchange_lane=True)
+    comm.exchange_pairs([(0, x)], [(0, c1)])
+    comm.exchange_pairs([(0, a2)], [(0, c2)])
+    arrived = lanes.mark(on_exchange_lane=True)
+lanes.wait(arrived)
+y = c1 + 1
+torch.cuda.synchronize()
+assert torch.equal(y, a1 * 2 + 1) and torch.equal(c2, a2)
+dist.destroy_process_group()
+print("NCCL SELF OK")
+'''
+
+
+def test_torch_rccl_point_to_point_batches(tmp_path):
+    """The transport of the N > 1 path on real RCCL, as far as one GPU can take it: torch.distributed's "nccl" backend (= RCCL) with
+    a one-rank group whose only peer is itself -- Comm.exchange_pairs with TWO messages to the same peer in one batch (the pulled
+    and the pushed half of a region), and two batches back to back on the exchange lane behind events (early_pull)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "nccl_self.py"
+    script.write_text(NCCL_SELF)
+    res = subprocess.run([__import__("sys").executable, str(script), str(port), ROOT], capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0 and "NCCL SELF OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
