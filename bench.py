@@ -611,6 +611,7 @@ def main():
             sg.propagate(state, a, K, early_pull=best["early_pull"])
         halo = sg.halo_stats()
         halo.update(chunks=best["chunks"], early_pull=best["early_pull"], variants_timed_before_the_run=variants,
+                    overlap_probe=getattr(sg.comm, "overlap_probe", None),
                     chosen=dict(best), pull_rows_sent=sg.n_send_pull_max, push_rows_sent=sg.n_send_push_max)
 
     def barrier():

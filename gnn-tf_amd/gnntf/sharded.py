@@ -259,6 +259,85 @@ class Comm:
         if self.size > 1:
             dist.barrier(group=self.group)
 
+    # ---- which streams carry the exchanges ----------------------------------------------------------------------------------
+    def tune_overlap(self, device, force=False, lanes=4, groups=4):
+        """Places the exchange so that transfers run BESIDE the compute stream's kernels.  HIP multiplexes streams onto a few
+        hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise), and two streams matter here: the exchange lane, which
+        holds the event waits around every RCCL group call, and the stream torch gives the process group for RCCL's own kernels.
+        When either shares the compute stream's hardware queue its packets queue up with the compute kernels and a transfer costs
+        its whole duration instead of hiding under the other column chunk's SpMM -- measured on MI355X: about one stream in four,
+        for both (tools/overlap_probe3.py, profiles/NOTES.md).  Probe: a send / recv of this rank to ITSELF, issued from each of
+        a few fresh lane streams, beside a few matrix products of the compute stream; when no lane hides the transfer on some
+        rank the group's own stream is the one in the way, and the probe repeats on a fresh process group (up to ``groups``).
+        The lane is each rank's own choice (``self.lane_stream``); the group is agreed on (``self.group``).  Collective; a no-op
+        for one rank, for sub-groups of a process grid, and for backends other than "nccl".  Returns the probe table (kept in
+        ``self.overlap_probe``)."""
+        if getattr(self, "overlap_probe", None) is not None:
+            return self.overlap_probe
+        self.overlap_probe, self.lane_stream = [], None
+        if device.type != "cuda" or self.solo or self.group is not None or not dist.is_initialized() or dist.get_backend() != "nccl":
+            return self.overlap_probe
+        if self.size == 1 and not force:
+            return self.overlap_probe
+        me = dist.get_rank()
+        A = torch.randn(4096, 4096, device=device)
+        B = torch.randn(4096, 4096, device=device)
+        C = torch.empty_like(A)
+        src = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()         # 1 GiB message: about a millisecond of RCCL kernel
+        dst = torch.empty_like(src)
+        HIDES = 0.75                                                       # measured: 0.5-0.6 beside the products when placed well, 0.85-1.1 when not
+
+        def products():
+            for _ in range(8):
+                torch.mm(A, B, out=C)
+
+        def transfer(lane, group):
+            with torch.cuda.stream(lane):
+                for _ in range(2):
+                    for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, dst, me, group), dist.P2POp(dist.isend, src, me, group)]):
+                        req.wait()
+
+        def ms(fn):
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(device)
+                dt = (time.perf_counter() - t0) * 1e3
+                best = dt if best is None else min(best, dt)
+            return best
+
+        streams = [torch.cuda.Stream(device) for _ in range(max(1, lanes))]
+        self._probe_lanes = streams                                        # kept alive: a freed stream's queue slot would be handed out again
+        chosen = None                                                      # (worst rank's share, group, this rank's lane, labels)
+        for g in range(max(1, groups)):
+            group = None if g == 0 else dist.new_group(list(range(dist.get_world_size())), backend="nccl")
+            transfer(streams[0], group)                                    # (first call of a group: communicator and stream set-up, untimed)
+            t_c = ms(products)
+            mine = None
+            for k, lane in enumerate(streams):
+                t_x = ms(lambda: transfer(lane, group))
+                t_both = ms(lambda: (transfer(lane, group), products()))
+                exposed = max(t_both - t_c, 0.0) / max(t_x, 1e-6)          # share of the transfer that did NOT hide
+                self.overlap_probe.append(dict(group=g, lane=k, products_ms=t_c, transfer_ms=t_x, together_ms=t_both, exposed_share=exposed))
+                if mine is None or exposed < mine[0] - 0.1:                # (ties: the first)
+                    mine = (exposed, lane, k)
+                if exposed < HIDES:
+                    break
+            flag = torch.tensor([mine[0]], dtype=torch.float64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)                    # the step takes the slowest rank's time
+            worst = float(flag.item())
+            if chosen is None or worst < chosen[0] - 0.1:
+                chosen = (worst, group, mine[1], (g, mine[2]))
+            if worst < HIDES:
+                break
+        self.group, self.lane_stream = chosen[1], chosen[2]
+        for rec in self.overlap_probe:
+            rec["chosen"] = (rec["group"], rec["lane"]) == chosen[3]
+        self.overlap_exposed_worst_rank = chosen[0]
+        return self.overlap_probe
+
     def alltoallv(self, chunks):
         """chunks[q]: a 1-D tensor for group rank q (any length).  Returns what every rank sent to this one."""
         if self.size == 1:
@@ -390,10 +469,10 @@ class _Lanes:
     """Two in-order lanes -- compute (the caller's stream) and exchange (a stream of its own) -- joined by
     events.  On CPU ranks there are no streams and everything runs in program order."""
 
-    def __init__(self, device):
+    def __init__(self, device, exchange_stream=None):
         self.gpu = device.type == "cuda"
         self.device = device
-        self._comm = torch.cuda.Stream(device) if self.gpu else None
+        self._comm = (exchange_stream if exchange_stream is not None else torch.cuda.Stream(device)) if self.gpu else None
 
     def exchange_lane(self):
         return torch.cuda.stream(self._comm) if self.gpu else contextlib.nullcontext()
@@ -498,6 +577,11 @@ class ShardedGraph:
         if self.world == 1:
             self._build_single_block(rowptr, colidx, nvals, relabel)
         else:
+            if hasattr(self.comm, "tune_overlap"):
+                self.comm.tune_overlap(dev)                  # (once per Comm) an exchange-lane stream whose transfers run beside the compute stream
+                self.group = self.comm.group
+                if getattr(self.comm, "lane_stream", None) is not None:
+                    self._lanes = _Lanes(dev, self.comm.lane_stream)
             self._build_block(rowidx.to(torch.int64), colidx.to(torch.int64), nvals, split_rows)
 
     # ---- one vertex block: no exchange -----------------------------------------------------------------

@@ -71,6 +71,19 @@ lanes.wait(arrived)
 y = c1 + 1
 torch.cuda.synchronize()
 assert torch.equal(y, a1 * 2 + 1) and torch.equal(c2, a2)
+# placement of the exchange: the probe must end on a lane stream and a group whose transfers hide beside the compute stream's kernels
+real = sharded.Comm(group=None)
+table = real.tune_overlap(dev, force=True)
+print("overlap probe:", table)
+chosen = [rec for rec in table if rec["chosen"]]
+assert len(chosen) == 1 and chosen[0]["exposed_share"] < 0.75, table   # measured: 0.5-0.6 when placed well, 0.85-1.1 when a queue is shared
+assert real.lane_stream is not None
+x2, y2 = torch.arange(64., device=dev), torch.zeros(64, device=dev)
+real.size, real.rank = 2, -1                      # (as SelfPeer: exchange with "rank 0" = itself, over the group the probe settled on)
+with torch.cuda.stream(real.lane_stream):
+    real.exchange_pairs([(0, x2)], [(0, y2)])
+torch.cuda.synchronize()
+assert torch.equal(x2, y2)
 dist.destroy_process_group()
 print("NCCL SELF OK")
 '''

@@ -26,9 +26,9 @@ from gnntf import sharded
 
 
 class LoopbackComm(sharded.Comm):
-    def __init__(self, world, rank, degrees):
+    def __init__(self, world, rank, degrees, transport="copy"):
         self.group, self.solo, self.rank, self.size = None, False, rank, world
-        self.degrees, self.sg, self.calls = degrees, None, 0
+        self.degrees, self.sg, self.calls, self.transport = degrees, None, 0, transport
 
     def _staged(self, t):
         return False
@@ -48,10 +48,25 @@ class LoopbackComm(sharded.Comm):
         self.exchange_pairs(list(enumerate(send_chunks)), list(enumerate(recv_chunks)))
 
     def exchange_pairs(self, sends, recvs):
-        for (_, s), (_, r) in zip(sends, recvs):        # about the same sizes by symmetry: stand in for the peer's rows
-            if s is not None and r is not None:
+        pairs = [(s, r) for (_, s), (_, r) in zip(sends, recvs) if s is not None and r is not None and min(s.shape[0], r.shape[0]) > 0]
+        if self.transport == "rccl":
+            # the same rows through REAL RCCL point-to-point kernels: this one-rank group is its own peer, so every message is an
+            # ncclSend / ncclRecv pair inside one group -- no link, but RCCL's kernels, their CUs and the host cost of the batch
+            import torch.distributed as dist
+            ops = []
+            for s, r in pairs:
                 m = min(s.shape[0], r.shape[0])
-                r[:m].copy_(s[:m])
+                ops.append(dist.P2POp(dist.irecv, r[:m], 0))
+            for s, r in pairs:
+                m = min(s.shape[0], r.shape[0])
+                ops.append(dist.P2POp(dist.isend, s[:m], 0))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            return
+        for s, r in pairs:                               # about the same sizes by symmetry: stand in for the peer's rows
+            m = min(s.shape[0], r.shape[0])
+            r[:m].copy_(s[:m])
 
     def all_gather_vec(self, t):                        # push_counts table: table[q][me] = rows q asks me to sum for it
         table = [torch.zeros_like(t) for _ in range(self.size)]
@@ -111,7 +126,16 @@ def main():
     ap.add_argument("--cover", default="cover")
     ap.add_argument("--chunks", type=int, default=2)
     ap.add_argument("--whole-rows", action="store_true")
+    ap.add_argument("--early-pull", action="store_true")
+    ap.add_argument("--dummy-streams", type=int, default=0, help="streams created before the process group (transport rccl)")
+    ap.add_argument("--transport", choices=["copy", "rccl"], default="copy",
+                    help="loop-back exchange by device copies, or through RCCL send / recv pairs of a one-rank group (its own peer)")
     a = ap.parse_args()
+    if a.transport == "rccl":
+        import torch.distributed as dist
+        _keep = [torch.cuda.Stream(torch.device("cuda:0")) for _ in range(a.dummy_streams)]      # shifts which hardware queue RCCL's stream lands on
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
     dev = torch.device("cuda:0")
     gnntf.set_default_device(dev)
     P, r, N = a.world, a.rank, a.nodes
@@ -127,7 +151,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     t0 = time.time()
-    comm = LoopbackComm(P, r, degrees)
+    comm = LoopbackComm(P, r, degrees, a.transport)
     sg = SimGraph(idx, vals, bounds, comm=comm, cover=a.cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True)
     sg.entries = None
     del idx, vals, comm.mirrored
@@ -158,17 +182,17 @@ def main():
         "pack_pushed_sums": part_ms(lambda: [sg._pack(state, c, state.bufs[c][1], "push") for c in every]),
         "first_iterations_interior_rows": part_ms(lambda: [sg._compute(state, c, src(c), dst(c), 0.1, interior=True, skip_empty=False) for c in every]),
     }
-    sg.propagate(state, 0.1, 10)
+    sg.propagate(state, 0.1, 10, early_pull=a.early_pull)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(3):
-        sg.propagate(state, 0.1, 10)
+        sg.propagate(state, 0.1, 10, early_pull=a.early_pull)
     torch.cuda.synchronize()
     t_step = (time.time() - t0) / 3
     st = sg.stats
     halo_rows = st["pull_rows"] + st["push_rows"]
     out = {"world": P, "rank": r, "graph": {"nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
-           "split_rows": bool(sg.split_rows)}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
+           "split_rows": bool(sg.split_rows), "early_pull": a.early_pull, "transport": a.transport}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
            "local_entries": sg.nnz_local, "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
            "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
            "kernels_breakdown_ms": breakdown, "loopback_copy_ms_per_iteration": t_x * 1e3, "step_ms_K10_loopback": t_step * 1e3,
