@@ -16,6 +16,7 @@
 // 64-byte-per-row A loads no longer hide (a 256 -> 7 product ran at 3.2 TB/s); the chunked kernel's eight blocks per CU do.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "gnx_internal.h"
 
@@ -304,6 +305,181 @@ int launch_ring(const DenseArgs &p, hipStream_t s) {
     return launch_ring_as<NT, 8, 2>(p, s);
 }
 
+// ---- W in REGISTERS, X through a deep LDS-DMA ring ---------------------------------------------------------------------------------
+// When the whole W fits the register file -- (F / 4) x NT fragments per lane, 256 for the pre-MLP's 256 -> 64 -- a wave keeps it there
+// for the life of the (persistent) block: no LDS read per MFMA at all, and the CU's LDS is ALL staging ring.  One wave per SIMD (512
+// registers each), so the matrix pipe is fed by a single straight-line instruction stream, and everything that is not an MFMA has to
+// sit in the issue slots between two of them:
+//   * W is the MFMA's A operand and the X fragment its B operand (out^T = W^T X^T): a lane then holds FOUR CONSECUTIVE output columns
+//     of one row, so a tile is stored with four 16-byte stores instead of sixteen 4-byte ones;
+//   * two accumulator sets: the stores of tile t are in the same basic block as the first MFMAs of the wave's next tile (no branch:
+//     only the wave's LAST tile, the one that can be ragged, takes the guarded path);
+//   * staging addresses are 32-bit row x 32-bit pitch (one v_mad_u64_u32 per load); the stage's K offset and LDS slot are compile-time;
+//   * staging never stops (past the wave's last tile it re-stages the last row tile, which nobody reads), so "all but the youngest
+//     4 (RING - 2) vector-memory operations" is the wait for every stage (stores in between only make it stricter).
+// Same k order as the other two kernels: same bits.  Measured (10M x 256 -> 64, profiles/NOTES.md): the ring depth does not matter from
+// 4 stages up and the staging waits are never taken -- what the launch costs beyond the MFMAs is issue slots and the clock.
+template <int NT, int KS, int RING, bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dense_wreg(const DenseArgs p, int64_t n_tiles64) {
+    constexpr int STAGE = 16 * RING_BK;
+    extern __shared__ float lds[];                                // [4 waves][RING][STAGE]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    float *__restrict__ ring = lds + wave * (RING * STAGE);
+    // W fragments: wreg[kc][T][t][nt] = W[64 kc + 16 T + 4 g + t][16 nt + c]
+    float wreg[KS][4][4][NT];
+#pragma unroll
+    for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                {
+                    wreg[kc][T][t][nt] = p.W[(int64_t)(64 * kc + 16 * T + 4 * g + t) * p.ldw + 16 * nt + c];
+                    asm volatile("" : "+a"(wreg[kc][T][t][nt]));      // W lives in the accumulation half of the register file; the MFMAs read it there
+                }
+    f32x4 bias[NT];                                               // columns 16 nt + 4 g .. + 3
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[nt][r] = p.bias ? p.bias[16 * nt + 4 * g + r] : 0.f;
+
+    const uint32_t n_tiles = (uint32_t)n_tiles64, n_rows = (uint32_t)p.n;
+    const uint32_t tile_stride = gridDim.x * 4, first = blockIdx.x * 4 + wave;
+    const uint32_t x_pitch = (uint32_t)p.ldx * 4u, o_pitch = (uint32_t)p.ldo * 4u;      // bytes
+    const char *__restrict__ Xb = reinterpret_cast<const char *>(p.X);
+    char *__restrict__ Ob = reinterpret_cast<char *>(p.out);
+    uint32_t piece[4];                                            // byte offset of this lane's 16-byte piece inside the stage's 256 bytes of row 4 i + g
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece[i] = 16u * (uint32_t)(c ^ (4 * i + g));
+    uint32_t pf_tile = first;
+    auto issue = [&](int pf_kc, int slot) {                       // both compile-time at every call site
+        const uint32_t t16 = (pf_tile < n_tiles ? pf_tile : n_tiles - 1) * 16u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t row = t16 + 4 * i + g;
+            row = row < n_rows ? row : n_rows - 1;                // rows past the end read a valid row and are not stored
+            const char *src = Xb + (uint64_t)row * x_pitch + (uint32_t)(pf_kc * RING_BK * 4) + piece[i];
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src), ring + slot * STAGE + i * 256, 16, 0, 0);
+        }
+        if (pf_kc == KS - 1) pf_tile += tile_stride;
+    };
+    auto fragments = [&](int slot, f32x4 (&a)[4]) {               // X[row c][16 T + 4 g .. + 3] of the stage in `slot`
+        const float *__restrict__ A = ring + slot * STAGE;
+#pragma unroll
+        for (int T = 0; T < 4; ++T) a[T] = *reinterpret_cast<const f32x4 *>(A + c * RING_BK + 4 * ((4 * T + g) ^ c));
+    };
+    // D layout with W as the A operand: lane (c, g), register r -> row c, column 16 nt + 4 g + r
+    auto finish = [&](const f32x4 &acc, int nt) {
+        f32x4 v = acc + bias[nt];
+        if constexpr (RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        return v;
+    };
+    auto store_tile = [&](f32x4 (&acc)[NT], uint32_t tile) {      // a full tile: no guards
+        char *o = Ob + (uint64_t)(tile * 16u + c) * o_pitch + 16u * g;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(o + 64 * nt) = finish(acc[nt], nt);
+    };
+    auto store_last = [&](f32x4 (&acc)[NT], uint32_t tile) {      // the wave's last tile: may be the ragged one
+        const uint32_t row = tile * 16u + c;
+        if (row < n_rows) {
+            char *o = Ob + (uint64_t)row * o_pitch + 16u * g;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(o + 64 * nt) = finish(acc[nt], nt);
+        }
+    };
+    f32x4 afrag[2][4];                                            // the X fragments of the stage being multiplied and of the next one
+    // one tile: KS stages; `slot0` is the ring slot of its first stage (compile-time).  With EPI, the stores of the wave's previous tile
+    // sit among the first stage's MFMAs.
+    auto tile_body = [&](auto epi, int slot0, f32x4 (&acc)[NT], f32x4 (&prev)[NT], uint32_t prev_tile) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) {
+            const int slot = (slot0 + kc) % RING;
+            f32x4 (&a_cur)[4] = afrag[kc & 1];
+            f32x4 (&a_nxt)[4] = afrag[(kc + 1) & 1];
+            // a_cur was read out of `slot`; the slot before it is free (its fragments were consumed by the previous stage's MFMAs)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue((kc + RING - 1) % KS, (slot + RING - 1) % RING);
+            if constexpr (decltype(epi)::value) {
+                if (kc == 0) store_tile(prev, prev_tile);
+            }
+#pragma unroll
+            for (int T = 0; T < 3; ++T)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[kc][T][t][nt], a_cur[T][t], acc[nt], 0, 0, 0);
+            // the next stage: RING - 2 younger stages may still be in flight behind it
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING - 2)) : "memory");
+            fragments((slot + 1) % RING, a_nxt);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[kc][3][t][nt], a_cur[3][t], acc[nt], 0, 0, 0);
+        }
+    };
+    static_assert(KS % 2 == 0, "the fragment registers alternate per stage: a tile must start on the same one every time");
+    static_assert((2 * KS) % RING == 0, "two tiles must take a whole number of ring turns (their slots are compile-time)");
+    if (first < n_tiles) {
+#pragma unroll
+        for (int s0 = 0; s0 < RING - 1; ++s0) issue(s0 % KS, s0);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * (RING - 2)) : "memory");          // stage 0 has landed
+        fragments(0, afrag[0]);
+        f32x4 accA[NT], accB[NT];
+        uint32_t tile = first;
+        constexpr int SLOT_B = KS % RING;                         // first slot of every second tile
+        tile_body(std::false_type{}, 0, accA, accB, 0u);
+        for (;;) {
+            if (tile + tile_stride >= n_tiles) { store_last(accA, tile); break; }
+            tile_body(std::true_type{}, SLOT_B, accB, accA, tile);
+            tile += tile_stride;
+            if (tile + tile_stride >= n_tiles) { store_last(accB, tile); break; }
+            tile_body(std::true_type{}, 0, accA, accB, tile);
+            tile += tile_stride;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing of this wave may still be writing LDS when the block retires
+}
+
+// registers for W: (F / 4) x NT fragments per lane, at most 256 of the wave's 512
+bool wreg_eligible(const DenseArgs &p, bool x_aligned, int nt) {
+    const bool out_aligned = reinterpret_cast<uintptr_t>(p.out) % 16 == 0 && p.ldo % 4 == 0;
+    return x_aligned && out_aligned && p.in_rows == nullptr && p.out_rows == nullptr && p.F % RING_BK == 0 && (p.F / 4) * nt <= 256 && p.O == 16 * nt &&
+           p.n >= 16 * 1024 && p.n < (1ll << 31) && p.ldx < (1ll << 30) && p.ldo < (1ll << 30);
+}
+
+template <int NT, int KS, int RING, bool RELU>
+int launch_wreg_as(const DenseArgs &p, hipStream_t s) {
+    const size_t lds_bytes = (size_t)4 * RING * 16 * RING_BK * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_wreg<NT, KS, RING, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+        configured = true;
+    }
+    const int64_t n_tiles = (p.n + 15) / 16;
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<int64_t>((n_tiles + 3) / 4, cus);
+    hipLaunchKernelGGL((k_dense_wreg<NT, KS, RING, RELU>), dim3(grid), dim3(256), lds_bytes, s, p, n_tiles);
+    return GNX_OK;
+}
+
+template <int NT, int KS, int RING>
+int launch_wreg(const DenseArgs &p, hipStream_t s) {
+    return p.act == GNX_ACT_RELU ? launch_wreg_as<NT, KS, RING, true>(p, s) : launch_wreg_as<NT, KS, RING, false>(p, s);
+}
+
 template <int NT>
 void launch_dense(const DenseArgs &p, bool aligned, hipStream_t s) {
     const unsigned grid = (unsigned)((p.n + 16 * DENSE_WAVES - 1) / (16 * DENSE_WAVES));
@@ -572,6 +748,16 @@ static bool ring_enabled() {
 #endif
 }
 
+// (tuning builds: GNX_DENSE_WREG=0 skips the W-in-registers kernel)
+static bool wreg_enabled() {
+#ifdef GNX_TUNING
+    static const bool on = [] { const char *e = getenv("GNX_DENSE_WREG"); return !(e && e[0] == '0'); }();
+    return on;
+#else
+    return true;
+#endif
+}
+
 int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W, int64_t ldw, int64_t O, const float *bias, int act,
                const int32_t *in_rows, const int32_t *out_rows, float *out, int64_t ldo, hipStream_t s) {
     if (n == 0) return GNX_OK;
@@ -584,6 +770,15 @@ int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W
         q.O = (int)(O - o0 < 256 ? O - o0 : 256);
         const int nt = (q.O + 15) / 16;
         const int nt4 = nt;                                                // the ring kernel takes accumulator columns in whole groups of four
+        if (wreg_enabled() && wreg_eligible(q, al, nt)) {                 // shapes whose W fits the registers: (F / 4) x nt <= 256 fragments
+            int rc = -1;
+            if (q.F == 256 && nt == 4)      rc = launch_wreg<4, 4, 8>(q, s);
+            else if (q.F == 256 && nt == 2) rc = launch_wreg<2, 4, 8>(q, s);
+            else if (q.F == 128 && nt == 4) rc = launch_wreg<4, 2, 4>(q, s);
+            else if (q.F == 128 && nt == 8) rc = launch_wreg<8, 2, 4>(q, s);
+            if (rc > 0) return rc;
+            if (rc == GNX_OK) continue;
+        }
         if (ring_enabled() && nt % 4 == 0 && ring_eligible(q, al, nt4) && nt4 <= 16) {
             int rc = nt4 == 4 ? launch_ring<4>(q, s) : nt4 == 8 ? launch_ring<8>(q, s) : nt4 == 12 ? launch_ring<12>(q, s) : launch_ring<16>(q, s);
             if (rc != GNX_OK) return rc;

@@ -40,6 +40,36 @@ def test_dense_mfma_matches_float64(gnntf, n, F, O, relu):
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4 * np.sqrt(F))
 
 
+@pytest.mark.parametrize("n,F,O", [
+    # W in registers (k_dense_wreg): (F / 4) x (O / 16) <= 256 fragments per lane, O a multiple of 16
+    (20001, 256, 64), (16400, 256, 32), (33007, 128, 64), (17000, 128, 128), (1_000_003, 256, 64),
+    # X through the LDS-DMA ring with W in LDS (k_dense_ring): the other tall shapes with whole 64-float K chunks
+    (20001, 256, 128), (16385, 64, 64), (16400, 192, 256)])
+@pytest.mark.parametrize("relu,with_bias", [(False, True), (True, True), (True, False)])
+def test_dense_tall_kernels(gnntf, n, F, O, relu, with_bias):
+    """The persistent kernels of tall inputs (n >= 16K rows): against float64 on a sample of rows, BITWISE against the same product
+    computed in slabs of fewer than 16K rows (those take k_dense_mfma: all three kernels add the k terms in the same order), and with a
+    ragged last tile.  X = rows of the identity with an asymmetric W catches a transposed fragment map exactly."""
+    g = torch.Generator(device="cuda").manual_seed(n + F + O)
+    X = torch.randn(n, F, device="cuda", generator=g)
+    W = torch.randn(F, O, device="cuda", generator=g)
+    b = torch.randn(1, O, device="cuda", generator=g) if with_bias else None
+    got = gnntf.dense(X, W, b, relu=relu)
+    slabs = torch.cat([gnntf.dense(X[i:i + 8192], W, b, relu=relu) for i in range(0, n, 8192)])
+    assert torch.equal(got, slabs)
+    rows = torch.cat([torch.arange(0, 64), torch.randint(0, n, (2048,)), torch.arange(n - 64, n)]).cuda()
+    want = X[rows].double() @ W.double() + (b.double() if with_bias else 0.0)
+    want = torch.relu(want) if relu else want
+    np.testing.assert_allclose(got[rows].cpu().numpy(), want.cpu().numpy(), rtol=RTOL, atol=1e-4 * np.sqrt(F))
+    if not relu and not with_bias:
+        return
+    eye = torch.zeros(n, F, device="cuda")
+    eye[torch.arange(n), torch.arange(n) % F] = 1.0
+    Wa = (torch.arange(F * O, device="cuda", dtype=torch.float32).reshape(F, O) * 0.5 - 7)
+    out = gnntf.dense(eye, Wa, None)
+    assert torch.equal(out, Wa[torch.arange(n, device="cuda") % F])
+
+
 def test_dense_mfma_layout_and_strides(gnntf):
     """A = I with an ASYMMETRIC W catches a transposed fragment map; strided / unaligned operands take the scalar-load path."""
     W = (np.arange(48 * 40, dtype=np.float32).reshape(48, 40) * 0.5 - 7)          # W[i][j] != W[j][i]
