@@ -570,6 +570,164 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ X,
         }
 }
 
+// ---- the same gradient with the ACCUMULATORS stationary: every wave keeps a whole F x O partial in its registers --------------------
+// For F x O <= 16384 (256 x 64, 128 x 128, 64 x 64, ...: the layers of the path) one wave's 512 registers hold the complete result,
+// (F / 16) x (O / 16) accumulator tiles.  A wave then needs nobody: it owns a slab of rows, streams X[rows, :] and G[rows, :] through a
+// private LDS ring by LDS-DMA (whole lines, no VGPR staging, RING - 1 stages in flight behind a counted s_waitcnt vmcnt), and per 4 rows
+// reads F / 16 + O / 16 single-word fragments for (F / 16) (O / 16) MFMAs -- no barrier anywhere, nothing recomputed, and shapes narrower
+// than k_wgrad_mfma's 256-feature panel waste nothing.  The LDS image is lane-linear (an LDS-DMA cannot scatter), so the 16-byte pieces
+// of ODD rows are swapped in groups of four (piece ^ 4) on the source address: a half-wave's fragment read -- 2 rows x 16 consecutive
+// words -- then covers all 32 banks once.  G is the MFMA's A operand: a lane ends up with four consecutive outputs of one feature row
+// (16-byte stores of the partial).  The partials of the waves are added in wave order by k_sum_slabs (fixed order: reproducible).
+template <int MT, int NT> struct WgradAcc {
+    static constexpr int F = 16 * MT, O = 16 * NT, R = 8;                 // rows per stage
+    static constexpr int XI = R * F / 256, GI = R * O / 256, NI = XI + GI; // LDS-DMA instructions per stage
+    static constexpr int STAGE = R * (F + O);                             // floats
+    static constexpr int RING_FIT = (36 << 10) / (STAGE * 4);
+    static constexpr int RING = RING_FIT > 8 ? 8 : (RING_FIT < 2 ? 2 : RING_FIT);
+    static_assert(NI * (RING - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(MT * NT <= 64, "the accumulators must fit the register file");
+};
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_wgrad_acc(const float *__restrict__ X, uint32_t x_pitch, const float *__restrict__ G, uint32_t g_pitch, uint32_t n, uint32_t rows_per_wave,
+                 float *__restrict__ partial) {
+    using Cfg = WgradAcc<MT, NT>;
+    constexpr int F = Cfg::F, O = Cfg::O, R = Cfg::R, RING = Cfg::RING, STAGE = Cfg::STAGE;
+    extern __shared__ float lds[];                                // [4 waves][RING][STAGE: R rows of X | R rows of G]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const uint32_t wid = blockIdx.x * 4 + wave;
+    const uint32_t r_beg = wid * rows_per_wave;
+    if (r_beg >= n) return;                                       // (whole waves; there is no barrier in this kernel)
+    const uint32_t r_end = r_beg + rows_per_wave < n ? r_beg + rows_per_wave : n;
+    const uint32_t n_stages = (r_end - r_beg + R - 1) / R;
+    float *__restrict__ ring = lds + wave * (RING * STAGE);
+    const char *__restrict__ Xb = reinterpret_cast<const char *>(X);
+    const char *__restrict__ Gb = reinterpret_cast<const char *>(G);
+
+    // staging: instruction i of the X part fills slots 64 i .. 64 i + 63 of the stage's X image (slot = 16-byte piece, F / 4 per row)
+    uint32_t pf = 0, pf_slot = 0;
+    auto issue_next = [&]() {
+        const uint32_t row0 = r_beg + (pf < n_stages ? pf : n_stages - 1) * R;      // past the slab: the last stage again, which nobody reads
+        float *dst = ring + pf_slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < Cfg::XI; ++i) {
+            const uint32_t q = 64 * i + lane, r = q / (F / 4), piece = (q % (F / 4)) ^ (4 * (r & 1));
+            uint32_t row = row0 + r;
+            row = row < n ? row : n - 1;                          // rows past the end read a valid row; their fragments are zeroed
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(Xb + (uint64_t)row * x_pitch + 16 * piece), dst + i * 256, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::GI; ++i) {
+            const uint32_t q = 64 * i + lane, r = q / (O / 4), piece = (q % (O / 4)) ^ (4 * (r & 1));
+            uint32_t row = row0 + r;
+            row = row < n ? row : n - 1;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(Gb + (uint64_t)row * g_pitch + 16 * piece), dst + R * F + i * 256, 16, 0, 0);
+        }
+        ++pf;
+        pf_slot = pf_slot + 1 == RING ? 0 : pf_slot + 1;
+    };
+    // fragments of k step s (rows 4 s + g): word 16 t + c of the row sits in piece group t ^ (g & 1)
+    const int flip = g & 1;
+    const int x_lane = g * F + c, g_lane = g * O + c;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int ft = 0; ft < MT; ++ft)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto multiply = [&](auto masked, uint32_t slot, uint32_t valid_rows) {
+        const float *__restrict__ Xs = ring + slot * STAGE + x_lane;
+        const float *__restrict__ Gs = ring + slot * STAGE + R * F + g_lane;
+#pragma unroll
+        for (int s = 0; s < R / 4; ++s) {
+            float a[MT], b[NT];
+#pragma unroll
+            for (int ft = 0; ft < MT; ++ft) a[ft] = Xs[4 * s * F + 16 * (ft ^ flip)];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = Gs[4 * s * O + 16 * (nt ^ flip)];
+            if constexpr (decltype(masked)::value) {
+                if ((uint32_t)(4 * s + g) >= valid_rows) {        // 0 x 0: a row past the slab adds nothing, whatever the row that was read holds
+#pragma unroll
+                    for (int ft = 0; ft < MT; ++ft) a[ft] = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int ft = 0; ft < MT; ++ft)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[ft][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt], a[ft], acc[ft][nt], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < RING - 1; ++s0) issue_next();
+    uint32_t slot = 0;
+    for (uint32_t st = 0; st + 1 < n_stages; ++st) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the fragments of the stage whose slot is restaged next have been read
+        issue_next();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::NI * (RING - 1)) : "memory");    // all but the youngest RING - 1 stages: stage st has landed
+        multiply(std::false_type{}, slot, R);
+        slot = slot + 1 == RING ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (also: nothing of this wave may still be writing LDS when it retires)
+    multiply(std::true_type{}, slot, r_end - (r_beg + (n_stages - 1) * R));
+    // D layout with G as the A operand: lane (c, g), register r -> feature 16 ft + c, output 16 nt + 4 g + r
+    float *__restrict__ out = partial + (uint64_t)wid * (F * O);
+#pragma unroll
+    for (int ft = 0; ft < MT; ++ft)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(out + (16 * ft + c) * O + 16 * nt + 4 * g) = acc[ft][nt];
+}
+
+template <int MT, int NT>
+int launch_wgrad_acc(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t n, float *work, int64_t max_slabs, int64_t *n_slabs, hipStream_t s) {
+    using Cfg = WgradAcc<MT, NT>;
+    const size_t lds_bytes = (size_t)4 * Cfg::RING * Cfg::STAGE * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad_acc<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+        configured = true;
+    }
+    int cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int64_t waves = std::min<int64_t>((int64_t)cus * 4, max_slabs);
+    int64_t rows_per_wave = (n + waves - 1) / waves;
+    rows_per_wave = std::max<int64_t>((rows_per_wave + Cfg::R - 1) / Cfg::R * Cfg::R, 8 * Cfg::R);
+    waves = (n + rows_per_wave - 1) / rows_per_wave;
+    hipLaunchKernelGGL((k_wgrad_acc<MT, NT>), dim3((unsigned)((waves + 3) / 4)), dim3(256), lds_bytes, s, X, (uint32_t)(ldx * 4), G, (uint32_t)(ldg * 4),
+                       (uint32_t)n, (uint32_t)rows_per_wave, work);
+    *n_slabs = waves;
+    return GNX_OK;
+}
+
+// F, O in {32, 64, 128, 256} with F x O <= 16384, whole aligned rows; returns < 0 when the shape is not one of them
+int wgrad_acc_dispatch(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t n, int64_t F, int64_t O, bool aligned, float *work,
+                       int64_t max_slabs, int64_t *n_slabs, hipStream_t s) {
+    if (!aligned || n < 16 * 1024 || n >= (1ll << 31) || ldx >= (1ll << 30) || ldg >= (1ll << 30) || F * O > 16384) return -1;
+#define GNX_WGRAD_ACC(MT_, NT_) if (F == 16 * MT_ && O == 16 * NT_) return launch_wgrad_acc<MT_, NT_>(X, ldx, G, ldg, n, work, max_slabs, n_slabs, s)
+    GNX_WGRAD_ACC(2, 2); GNX_WGRAD_ACC(2, 4); GNX_WGRAD_ACC(2, 8); GNX_WGRAD_ACC(2, 16);
+    GNX_WGRAD_ACC(4, 2); GNX_WGRAD_ACC(4, 4); GNX_WGRAD_ACC(4, 8); GNX_WGRAD_ACC(4, 16);
+    GNX_WGRAD_ACC(8, 2); GNX_WGRAD_ACC(8, 4); GNX_WGRAD_ACC(8, 8);
+    GNX_WGRAD_ACC(16, 2); GNX_WGRAD_ACC(16, 4);
+#undef GNX_WGRAD_ACC
+    return -1;
+}
+
+// slabs [group * per, min(group * per + per, n_slabs)) added in order into out[group]: the first level of a two-level sum whose second
+// level is k_sum_slabs over the groups (fixed association: reproducible); blockIdx.y = group
+__global__ void k_sum_slab_groups(const float *__restrict__ partial, int64_t n_slabs, int64_t per, int64_t elems, float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= elems) return;
+    const int64_t s0 = (int64_t)blockIdx.y * per, s1 = s0 + per < n_slabs ? s0 + per : n_slabs;
+    float acc = 0.f;
+    for (int64_t s = s0; s < s1; ++s) acc += partial[s * elems + e];
+    out[(int64_t)blockIdx.y * elems + e] = acc;
+}
+
 __global__ void k_sum_slabs(const float *__restrict__ partial, int64_t n_slabs, int64_t elems, float *__restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= elems) return;
@@ -748,6 +906,16 @@ static bool ring_enabled() {
 #endif
 }
 
+// (tuning builds: GNX_WGRAD_ACC=0 keeps the panel kernel)
+static bool wgrad_acc_enabled() {
+#ifdef GNX_TUNING
+    static const bool on = [] { const char *e = getenv("GNX_WGRAD_ACC"); return !(e && e[0] == '0'); }();
+    return on;
+#else
+    return true;
+#endif
+}
+
 // (tuning builds: GNX_DENSE_WREG=0 skips the W-in-registers kernel)
 static bool wreg_enabled() {
 #ifdef GNX_TUNING
@@ -834,6 +1002,25 @@ int gnx_dense_wgrad(const float *d_X, int64_t ldx, const float *d_G, int64_t ldg
     rows_per_slab = (rows_per_slab + 31) / 32 * 32;
     const int64_t n_slabs = (n + rows_per_slab - 1) / rows_per_slab;
     const bool al = ldx % 4 == 0 && ldg % 4 == 0 && aligned16(d_X) && aligned16(d_G);
+    if (wgrad_acc_enabled() && aligned16(d_work)) {                          // the shapes whose whole result fits one wave's registers
+        int64_t waves = 0;
+        const int rc = wgrad_acc_dispatch(d_X, ldx, d_G, ldg, n, F, O, al, d_work, work_floats / fo > 2048 ? 2048 : work_floats / fo, &waves, s);
+        if (rc > 0) return rc;
+        if (rc == GNX_OK) {
+            // the waves' partials, added in wave order: in groups of 32 first when the scratch has room for the group sums (a sum over a
+            // thousand slabs of a few thousand elements is otherwise a launch of a few blocks walking a long chain each)
+            const int64_t per = 32, groups = (waves + per - 1) / per;
+            if (waves > 64 && work_floats >= (waves + groups) * fo) {
+                float *tmp = d_work + waves * fo;
+                hipLaunchKernelGGL(k_sum_slab_groups, dim3((unsigned)((fo + 255) / 256), (unsigned)groups), dim3(256), 0, s, d_work, waves, per, fo, tmp);
+                hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((fo + 255) / 256)), dim3(256), 0, s, tmp, groups, fo, d_dW);
+            } else {
+                hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)((fo + 255) / 256)), dim3(256), 0, s, d_work, waves, fo, d_dW);
+            }
+            GNX_HIP(hipGetLastError());
+            return GNX_OK;
+        }
+    }
     const int nt_all = (int)((O + 15) / 16);
     const int NTsel = nt_all >= 4 ? 4 : (nt_all >= 2 ? 2 : 1);
     dim3 grid((unsigned)n_slabs, (unsigned)((F + 255) / 256), (unsigned)((nt_all + NTsel - 1) / NTsel));

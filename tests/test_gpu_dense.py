@@ -119,6 +119,28 @@ def test_dense_weight_gradient_mfma(gnntf, n, F, O):
     np.testing.assert_allclose(_dense_wgrad(big[:, 3:3 + F], dev(G)).cpu().numpy(), want, rtol=RTOL, atol=2e-4 * np.sqrt(n))
 
 
+@pytest.mark.parametrize("n,F,O", [(16385, 64, 64), (20003, 256, 64), (17001, 128, 128), (33002, 32, 32), (16500, 64, 256), (50007, 128, 64),
+                                   (300_005, 256, 32), (1_000_003, 64, 64)])
+def test_dense_weight_gradient_accumulator_stationary(gnntf, n, F, O):
+    """k_wgrad_acc (tall inputs, F and O in {32, 64, 128, 256}, F x O <= 16384: every wave keeps a whole partial in registers): against
+    float64, bitwise repeatable, ragged slabs; and EXACTLY on integer-valued operands (X = rows of the identity: a transposed fragment or a
+    wrong LDS swizzle moves a sum to another cell)."""
+    from gnntf.sparse import _dense_wgrad
+    g = torch.Generator(device="cuda").manual_seed(n + F * O)
+    X = torch.randn(n, F, device="cuda", generator=g)
+    G = torch.randn(n, O, device="cuda", generator=g)
+    got = _dense_wgrad(X, G)
+    want = sum(X[i:i + 65536].double().t() @ G[i:i + 65536].double() for i in range(0, n, 65536))
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=RTOL, atol=2e-4 * np.sqrt(n))
+    assert torch.equal(got, _dense_wgrad(X, G))
+    rows = torch.arange(n, device="cuda")
+    eye = torch.zeros(n, F, device="cuda")
+    eye[rows, (rows * 7) % F] = 1.0
+    Gi = torch.randint(-3, 4, (n, O), device="cuda", generator=g).float()
+    exact = torch.zeros(F, O, device="cuda", dtype=torch.float64).index_add_(0, (rows * 7) % F, Gi.double())
+    assert torch.equal(_dense_wgrad(eye, Gi).double(), exact)
+
+
 def hub_graph(n, m, hub_entries, seed):
     """An R-MAT graph plus one hub row/column with more than LONG_ROW (512) entries."""
     coo, vals, shape = graphs.rmat_symmetric_coo(n, m, seed=seed)
