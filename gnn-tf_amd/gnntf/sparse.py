@@ -484,7 +484,7 @@ class _SpMMBiasAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
-        g = (g * (out > 0)) if ctx.relu else g
+        g = _relu_mask(g, out) if ctx.relu else g
         g = g.contiguous()
         gY = _launch(ctx.adj, g, None, 1.0, 0.0, nat.ACT_NONE, transposed=True) if ctx.needs_input_grad[0] else None
         gb = g.sum(dim=0, keepdim=True) if ctx.has_bias and ctx.needs_input_grad[1] else None
@@ -556,6 +556,11 @@ def _dense_launch(X, W, bias, relu):
     return out
 
 
+def _relu_mask(g, out):
+    """g * (out > 0) in one pass (relu's backward; ``out`` is a relu output, never NaN)."""
+    return torch.ops.aten.threshold_backward(g.contiguous(), out, 0.0)
+
+
 def _dense_wgrad(X, G):
     """dW = X^T . G on the matrix cores (gnx_dense_wgrad): row slabs, partial sums added in a fixed order."""
     X, G = _as_f32_rows(X), _as_f32_rows(G)
@@ -586,7 +591,7 @@ class _DenseAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         X, W, out = ctx.saved_tensors
-        g = (g * (out > 0)) if ctx.relu else g
+        g = _relu_mask(g, out) if ctx.relu else g
         g = g.contiguous()
         gX = _dense_launch(g, W.t().contiguous(), None, False) if ctx.needs_input_grad[0] else None
         gW = _dense_wgrad(X, g) if ctx.needs_input_grad[1] else None
@@ -631,7 +636,7 @@ class _GCNIIStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         T, M, out = ctx.saved_tensors
-        g = ((g * (out > 0)) if ctx.relu else g).contiguous()
+        g = (_relu_mask(g, out) if ctx.relu else g).contiguous()
         gM = _dense_wgrad(T, g) if ctx.needs_input_grad[2] else None
         gH = gH0 = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -773,7 +778,7 @@ class _SparseDense(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
-        g = ((g * (out > 0)) if ctx.relu else g).contiguous()
+        g = (_relu_mask(g, out) if ctx.relu else g).contiguous()
         gW = _launch(ctx.adj, g, None, 1.0, 0.0, nat.ACT_NONE, transposed=True) if ctx.needs_input_grad[0] else None
         gb = g.sum(dim=0, keepdim=True) if ctx.has_bias and ctx.needs_input_grad[1] else None
         return gW, gb, None, None
