@@ -572,8 +572,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ X,
 
 // ---- the same gradient with the ACCUMULATORS stationary: every wave keeps a whole F x O partial in its registers --------------------
 // For F x O <= 16384 (256 x 64, 128 x 128, 64 x 64, ...: the layers of the path) one wave's 512 registers hold the complete result,
-// (F / 16) x (O / 16) accumulator tiles (wider layers: one panel of features per wave, blockIdx.y walks the panels and G is read once
-// per panel; widths that are not 32 / 64 / 128 / 256 are padded inside the LDS image only).  A wave then needs nobody: it owns a slab of rows, streams X[rows, :] and G[rows, :] through a
+// (F / 16) x (O / 16) accumulator tiles (wider layers: one panel of at most 128 outputs x 16384 / 128 features per wave, every slab of
+// rows walked once per panel; widths that are not 32 / 64 / 128 / 256 are padded inside the LDS image only).  A wave then needs nobody: it owns a slab of rows, streams X[rows, :] and G[rows, :] through a
 // private LDS ring by LDS-DMA (whole lines, no VGPR staging, RING - 1 stages in flight behind a counted s_waitcnt vmcnt), and per 4 rows
 // reads F / 16 + O / 16 single-word fragments for (F / 16) (O / 16) MFMAs -- no barrier anywhere, nothing recomputed, and shapes narrower
 // than k_wgrad_mfma's 256-feature panel waste nothing.  The LDS image is lane-linear (an LDS-DMA cannot scatter), so the 16-byte pieces
@@ -593,7 +593,7 @@ template <int MT, int NT> struct WgradAcc {
 template <int MT, int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_wgrad_acc(const float *__restrict__ X, uint32_t x_pitch, int f_all, const float *__restrict__ G, uint32_t g_pitch, int o_all, uint32_t n,
-                 uint32_t rows_per_wave, uint32_t panels, float *__restrict__ partial) {
+                 uint32_t rows_per_wave, uint32_t f_panels, uint32_t panels, float *__restrict__ partial) {
     using Cfg = WgradAcc<MT, NT>;
     // F x O: the PANEL this wave accumulates (padded to whole 16-column tiles of a power-of-two count).  Columns past the real widths
     // stage a piece that exists (piece 0 of the row) and feed only accumulator cells that are never stored.
@@ -602,9 +602,10 @@ void k_wgrad_acc(const float *__restrict__ X, uint32_t x_pitch, int f_all, const
     constexpr int F = Cfg::F, O = Cfg::O, R = Cfg::R, RING = Cfg::RING, STAGE = Cfg::STAGE;
     const uint32_t bgroup = blockIdx.x / (8 * panels), brem = blockIdx.x % (8 * panels);
     const uint32_t slab_block = bgroup * 8 + brem % 8;
-    const int f0 = (int)(brem / 8) * F;
-    const uint32_t f_pieces = (uint32_t)((f_all - f0 < F ? f_all - f0 : F) / 4), o_pieces = (uint32_t)(o_all / 4);
+    const int f0 = (int)((brem / 8) % f_panels) * F, o0 = (int)((brem / 8) / f_panels) * O;       // panels = feature panels x output panels
+    const uint32_t f_pieces = (uint32_t)((f_all - f0 < F ? f_all - f0 : F) / 4), o_pieces = (uint32_t)((o_all - o0 < O ? o_all - o0 : O) / 4);
     X += f0;
+    G += o0;
     extern __shared__ float lds[];                                // [4 waves][RING][STAGE: R rows of X | R rows of G]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -689,12 +690,12 @@ void k_wgrad_acc(const float *__restrict__ X, uint32_t x_pitch, int f_all, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (also: nothing of this wave may still be writing LDS when it retires)
     multiply(std::true_type{}, slot, r_end - (r_beg + (n_stages - 1) * R));
     // D layout with G as the A operand: lane (c, g), register r -> feature 16 ft + c, output 16 nt + 4 g + r
-    float *__restrict__ out = partial + (uint64_t)wid * ((uint32_t)f_all * (uint32_t)o_all) + (uint32_t)f0 * (uint32_t)o_all;
+    float *__restrict__ out = partial + (uint64_t)wid * ((uint32_t)f_all * (uint32_t)o_all) + (uint32_t)f0 * (uint32_t)o_all + o0;
 #pragma unroll
     for (int ft = 0; ft < MT; ++ft)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            if (f0 + 16 * ft + c < f_all && 16 * nt + 4 * g < o_all)
+            if (f0 + 16 * ft + c < f_all && o0 + 16 * nt + 4 * g < o_all)
                 *reinterpret_cast<f32x4 *>(out + (16 * ft + c) * o_all + 16 * nt + 4 * g) = acc[ft][nt];
 }
 
@@ -711,31 +712,33 @@ int launch_wgrad_acc(const float *X, int64_t ldx, int64_t F, const float *G, int
     int cus = 256;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t panels = (F + Cfg::F - 1) / Cfg::F;
+    const int64_t f_panels = (F + Cfg::F - 1) / Cfg::F, panels = f_panels * ((O + Cfg::O - 1) / Cfg::O);
     int64_t waves = std::min<int64_t>(std::max<int64_t>((int64_t)cus * 4 / panels, 64), max_slabs);        // row slabs; every slab is walked once per panel
     int64_t rows_per_wave = (n + waves - 1) / waves;
     rows_per_wave = std::max<int64_t>((rows_per_wave + Cfg::R - 1) / Cfg::R * Cfg::R, 8 * Cfg::R);
     waves = (n + rows_per_wave - 1) / rows_per_wave;
     const int64_t slab_blocks = (waves + 3) / 4, grid = (slab_blocks + 7) / 8 * 8 * panels;
     hipLaunchKernelGGL((k_wgrad_acc<MT, NT>), dim3((unsigned)grid), dim3(256), lds_bytes, s, X, (uint32_t)(ldx * 4), (int)F, G, (uint32_t)(ldg * 4), (int)O,
-                       (uint32_t)n, (uint32_t)rows_per_wave, (uint32_t)panels, work);
+                       (uint32_t)n, (uint32_t)rows_per_wave, (uint32_t)f_panels, (uint32_t)panels, work);
     *n_slabs = waves;
     return GNX_OK;
 }
 
-// Whole aligned rows, F and O multiples of 4, O <= 256: the output width is padded to OP in {32, 64, 128, 256} and the features are cut
-// into panels of FP = 16384 / OP (at most 256) columns, each of which one wave holds.  Returns < 0 when the shape is not taken.
+// Whole aligned rows, F and O multiples of 4: the result is cut into panels of FP features x OP outputs, FP x OP <= 16384, each of which
+// one wave holds (OP = 32 / 64 / 128 >= O where that exists; FP = 16384 / OP, at most 256, narrower for narrow inputs); widths that
+// are not a power of two are padded inside the LDS image.  Returns < 0 when the shape is not taken.
 int wgrad_acc_dispatch(const float *X, int64_t ldx, const float *G, int64_t ldg, int64_t n, int64_t F, int64_t O, bool aligned, float *work,
                        int64_t max_slabs, int64_t *n_slabs, hipStream_t s) {
-    if (!aligned || n < 16 * 1024 || n >= (1ll << 31) || ldx >= (1ll << 30) || ldg >= (1ll << 30) || F % 4 || O % 4 || O > 256 || F * O >= (1ll << 31) ||
-        max_slabs < 64)
+    if (!aligned || n < 16 * 1024 || n >= (1ll << 31) || ldx >= (1ll << 30) || ldg >= (1ll << 30) || F % 4 || O % 4 || F * O >= (1ll << 31) || max_slabs < 64)
         return -1;
-    const int op = O <= 32 ? 32 : O <= 64 ? 64 : O <= 128 ? 128 : 256;
+    const int op = O <= 32 ? 32 : O <= 64 ? 64 : 128;
     int fp = std::min(16384 / op, 256);
     while (fp > 32 && fp / 2 >= F) fp /= 2;                                   // a narrow input does not need the widest panel
+    const int64_t panels = ((F + fp - 1) / fp) * ((O + op - 1) / op);
+    if (panels > 64) return -1;                                                // (very wide layers: every slab would be walked too often)
 #define GNX_WGRAD_ACC(MT_, NT_) if (fp == 16 * MT_ && op == 16 * NT_) return launch_wgrad_acc<MT_, NT_>(X, ldx, F, G, ldg, O, n, work, max_slabs, n_slabs, s)
-    GNX_WGRAD_ACC(2, 2); GNX_WGRAD_ACC(2, 4); GNX_WGRAD_ACC(2, 8); GNX_WGRAD_ACC(2, 16);
-    GNX_WGRAD_ACC(4, 2); GNX_WGRAD_ACC(4, 4); GNX_WGRAD_ACC(4, 8); GNX_WGRAD_ACC(4, 16);
+    GNX_WGRAD_ACC(2, 2); GNX_WGRAD_ACC(2, 4); GNX_WGRAD_ACC(2, 8);
+    GNX_WGRAD_ACC(4, 2); GNX_WGRAD_ACC(4, 4); GNX_WGRAD_ACC(4, 8);
     GNX_WGRAD_ACC(8, 2); GNX_WGRAD_ACC(8, 4); GNX_WGRAD_ACC(8, 8);
     GNX_WGRAD_ACC(16, 2); GNX_WGRAD_ACC(16, 4);
 #undef GNX_WGRAD_ACC

@@ -122,10 +122,10 @@ def test_dense_weight_gradient_mfma(gnntf, n, F, O):
 @pytest.mark.parametrize("n,F,O", [(16385, 64, 64), (20003, 256, 64), (17001, 128, 128), (33002, 32, 32), (16500, 64, 256), (50007, 128, 64),
                                    (300_005, 256, 32), (1_000_003, 64, 64),
                                    # widths padded to the next of {32, 64, 128, 256}; wide layers cut into feature panels
-                                   (70001, 64, 40), (20002, 100, 64), (16385, 256, 256), (30001, 256, 128), (17003, 520, 64), (40000, 128, 8),
+                                   (70001, 64, 40), (20002, 100, 64), (16385, 256, 256), (30001, 256, 128), (17003, 520, 64), (40000, 128, 8), (16400, 64, 300), (20000, 260, 132),
                                    (25000, 36, 12)])
 def test_dense_weight_gradient_accumulator_stationary(gnntf, n, F, O):
-    """k_wgrad_acc (tall inputs, widths multiples of 4, O <= 256: every wave keeps a whole panel of the result in registers): against
+    """k_wgrad_acc (tall inputs, widths multiples of 4: every wave keeps a whole panel of the result in registers): against
     float64, bitwise repeatable, ragged slabs; and EXACTLY on integer-valued operands (X = rows of the identity: a transposed fragment or a
     wrong LDS swizzle moves a sum to another cell)."""
     from gnntf.sparse import _dense_wgrad
