@@ -389,8 +389,16 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         t_dense = median_ms(lambda: gnntf.dense(X, W, b, relu=True), reps=5, warm=2)
         t_torch = median_ms(lambda: torch.relu(torch.addmm(b, X, W)), reps=5, warm=2)      # hipBLASLt GEMM + separate bias / relu passes
     mf["dense_10M_x_256_to_64_relu"] = {"ms": t_dense, "torch_addmm_relu_ms": t_torch, "TFLOPs": 2.0 * n * 256 * 64 / t_dense / 1e9, "GBs": (n * 256 * 4 + n * 64 * 4) / t_dense / 1e6,
-                                        "mfma_peak_TFLOPs": 157.3, "what": "gnx_dense, float32 v_mfma_f32_16x16x4_f32; X read once from HBM"}
-    del X
+                                        "mfma_peak_TFLOPs": 157.3, "what": "gnx_dense (k_dense_wreg: W in registers, X through an LDS-DMA ring), float32 "
+                                                                           "v_mfma_f32_16x16x4_f32; X read once from HBM"}
+    from gnntf.sparse import _dense_wgrad
+    Gd = torch.randn(n, 64, device=device)
+    t_wgrad = median_ms(lambda: _dense_wgrad(X, Gd), reps=5, warm=2)
+    t_wgrad_torch = median_ms(lambda: X.t() @ Gd, reps=3, warm=1)
+    mf["dense_wgrad_10M_x_256_x_64"] = {"ms": t_wgrad, "torch_matmul_ms": t_wgrad_torch, "TFLOPs": 2.0 * n * 256 * 64 / t_wgrad / 1e9,
+                                        "GBs": (n * 256 * 4 + n * 64 * 4) / t_wgrad / 1e6,
+                                        "what": "gnx_dense_wgrad (k_wgrad_acc: every wave keeps a whole 256 x 64 partial in registers), dW = X^T . G"}
+    del X, Gd
     logits = torch.randn(n, 40, device=device)
     nodes = torch.randperm(n, device=device)[:1_000_000]
     labels = torch.randint(0, 40, (1_000_000,), device=device)
