@@ -11,6 +11,9 @@
 // the A operand (16 bytes per lane; the k index inside a 16-wide step is permuted so that a lane's four consecutive floats
 // feed four MFMAs), W streams through LDS in K chunks shared by the block (row stride = 4 mod 32 banks: the four k-groups
 // of a wave read disjoint banks).  Arithmetic intensity is O/2 flop per byte of X: HBM-bound up to O = 32, MFMA-bound beyond.
+// Tall inputs (n >= 16K rows) take one of two persistent kernels instead: k_dense_wreg (W in registers, shapes up to 256 x 64) or
+// k_dense_ring (W in LDS); both stream X through per-wave LDS-DMA rings and add the k terms in the same order as this kernel.
+// gnx_dense_wgrad: k_wgrad_acc (accumulators stationary, tall inputs) or k_wgrad_mfma.
 // Tried and dropped (round 2): a persistent W-resident variant (W once in LDS, the whole K extent of a 16-row tile in
 // registers, next tile prefetched, no barrier in the loop) -- 5.1 ms vs 4.2 ms at 10M x 256 -> 64: with two waves per SIMD the
 // 64-byte-per-row A loads no longer hide (a 256 -> 7 product ran at 3.2 TB/s); the chunked kernel's eight blocks per CU do.
