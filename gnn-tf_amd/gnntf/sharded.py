@@ -578,7 +578,11 @@ class ShardedGraph:
             self._build_single_block(rowptr, colidx, nvals, relabel)
         else:
             if hasattr(self.comm, "tune_overlap"):
-                self.comm.tune_overlap(dev)                  # (once per Comm) an exchange-lane stream whose transfers run beside the compute stream
+                try:                                         # (once per Comm) an exchange-lane stream whose transfers run beside the compute stream
+                    self.comm.tune_overlap(dev)
+                except Exception as exc:                     # placement is an optimisation: a probe that cannot run (memory, a transport
+                    self.comm.overlap_probe = [{"error": repr(exc)}]        # without self-sends) leaves the defaults in place
+                    self.comm.lane_stream = None
                 self.group = self.comm.group
                 if getattr(self.comm, "lane_stream", None) is not None:
                     self._lanes = _Lanes(dev, self.comm.lane_stream)
