@@ -903,7 +903,7 @@ const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
 template <int VEC>
 const char *launch_rows_and_chunks(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
-    if (lanes > 32 || p.n_long == 0 || p.n_rows >= SMALL_ROWS || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;
+    if (lanes > 32 || p.n_long == 0 || (p.n_rows >= SMALL_ROWS && !(p.tune & 65536)) || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;   // (65536: tuning builds' A/B of the merged launch on big graphs)
     const unsigned cb = blocks_for(p.n_chunks, 4);
     const char *name;
 #define GNX_BOTH(G, RPB_, PIPE_)                                                                                          \

@@ -70,6 +70,32 @@ def test_dense_tall_kernels(gnntf, n, F, O, relu, with_bias):
     assert torch.equal(out, Wa[torch.arange(n, device="cuda") % F])
 
 
+@pytest.mark.parametrize("F,O", [(256, 64), (128, 128), (256, 128), (64, 64)])
+def test_dense_tall_kernels_with_pitched_operands(gnntf, F, O):
+    """The C entry with leading dimensions larger than the rows (X and out as aligned column slices of wider matrices): the persistent
+    kernels compute their addresses from 32-bit rows x byte pitches.  Same bits as the contiguous call; the columns beside the
+    result are not touched.  Likewise gnx_dense_wgrad on aligned slices."""
+    from gnntf import _native as nat
+    from gnntf.sparse import _dense_wgrad
+    n = 20011
+    g = torch.Generator(device="cuda").manual_seed(F * O)
+    wide = torch.randn(n, F + 96, device="cuda", generator=g)
+    X = wide[:, 32:32 + F]                                   # pitch F + 96, offset 128 bytes
+    W = torch.randn(F, O, device="cuda", generator=g)
+    b = torch.randn(O, device="cuda", generator=g)
+    want = gnntf.dense(X.contiguous(), W, b, relu=True)
+    assert torch.equal(gnntf.dense(X, W, b, relu=True), want)
+    out_wide = torch.full((n, O + 64), -7.0, device="cuda")
+    with nat.on_device(X.device):
+        nat.check(nat.lib().gnx_dense(nat.ptr(X), X.stride(0), n, F, nat.ptr(W), W.stride(0), O, nat.ptr(b), nat.ACT_RELU,
+                                      out_wide.data_ptr() + 4 * 32, out_wide.stride(0), nat.current_stream()))
+    assert torch.equal(out_wide[:, 32:32 + O], want)
+    assert bool((out_wide[:, :32] == -7.0).all()) and bool((out_wide[:, 32 + O:] == -7.0).all())
+    gwide = torch.randn(n, O + 32, device="cuda", generator=g)
+    G = gwide[:, 16:16 + O]
+    assert torch.equal(_dense_wgrad(X, G), _dense_wgrad(X.contiguous(), G.contiguous()))
+
+
 def test_dense_mfma_layout_and_strides(gnntf):
     """A = I with an ASYMMETRIC W catches a transposed fragment map; strided / unaligned operands take the scalar-load path."""
     W = (np.arange(48 * 40, dtype=np.float32).reshape(48, 40) * 0.5 - 7)          # W[i][j] != W[j][i]

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--feats", type=str, default="8,16,32")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--only", type=str, default="", help="comma-separated variant names to run (default: all)")
+    ap.add_argument("--variants", type=str, default="", help="name:tune,... replaces the built-in variant list (tuning build's gnx_debug_set_tune bits)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     gnntf.set_default_device(dev)
@@ -41,6 +42,8 @@ def main():
                                                         nat.current_stream()))
         res = {}
         variants = (("coop_index_fetch", 0), ("per_lane_index_fetch", 32768), ("coop_all_gathers_hit", 16384), ("per_lane_all_gathers_hit", 16384 | 32768))
+        if a.variants:
+            variants = tuple((v.split(":")[0], int(v.split(":")[1])) for v in a.variants.split(","))
         if a.only:
             variants = tuple(v for v in variants if v[0] in a.only.split(","))
         for name, tune in variants if tunable else (("default", None),):
