@@ -193,7 +193,7 @@ def main():
     halo_rows = st["pull_rows"] + st["push_rows"]
     out = {"world": P, "rank": r, "graph": {"nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
            "split_rows": bool(sg.split_rows), "early_pull": a.early_pull, "transport": a.transport}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
-           "local_entries": sg.nnz_local, "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
+           "local_entries": sg.nnz_local, "push_graph_entries": (sg.push_graph.nnz if sg.push_graph is not None else 0), "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
            "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
            "kernels_breakdown_ms": breakdown, "loopback_copy_ms_per_iteration": t_x * 1e3, "step_ms_K10_loopback": t_step * 1e3,
            "predicted_iteration_ms": {f"{bw}_GBs_per_link": max(t_c * 1e3, halo_rows * C * 4 / ((P - 1) * bw * 1e9) * 1e3) for bw in (30, 45, 60, 75)},
