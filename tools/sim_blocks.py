@@ -49,6 +49,10 @@ class LoopbackComm(sharded.Comm):
 
     def exchange_pairs(self, sends, recvs):
         pairs = [(s, r) for (_, s), (_, r) in zip(sends, recvs) if s is not None and r is not None and min(s.shape[0], r.shape[0]) > 0]
+        per_peer = {}
+        for (q, s), (_, r) in zip(sends, recvs):
+            if s is not None and r is not None:
+                per_peer[q] = per_peer.get(q, 0) + min(s.shape[0], r.shape[0]) * s.shape[1] * 4
         if self.transport == "rccl":
             # the same rows through REAL RCCL point-to-point kernels: this one-rank group is its own peer, so every message is an
             # ncclSend / ncclRecv pair inside one group -- no link, but RCCL's kernels, their CUs and the host cost of the batch
@@ -63,6 +67,13 @@ class LoopbackComm(sharded.Comm):
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+            return
+        if self.transport.startswith("sleep"):
+            # a transfer that takes link time but neither HBM bandwidth nor CUs: one spinning thread for as long as the busiest of the
+            # (parallel) links would need at the given rate -- what is left of the step beyond max(kernels, exchange) is the schedule's
+            worst = max(per_peer.values(), default=0)
+            if worst:
+                torch.cuda._sleep(int(worst / (self.link_GBs * 1e9) * self.spin_per_s))
             return
         for s, r in pairs:                               # about the same sizes by symmetry: stand in for the peer's rows
             m = min(s.shape[0], r.shape[0])
@@ -128,8 +139,10 @@ def main():
     ap.add_argument("--whole-rows", action="store_true")
     ap.add_argument("--early-pull", action="store_true")
     ap.add_argument("--dummy-streams", type=int, default=0, help="streams created before the process group (transport rccl)")
-    ap.add_argument("--transport", choices=["copy", "rccl"], default="copy",
-                    help="loop-back exchange by device copies, or through RCCL send / recv pairs of a one-rank group (its own peer)")
+    ap.add_argument("--transport", default="copy",
+                    help="loop-back exchange by device copies (copy), through RCCL send / recv pairs of a one-rank group (rccl), or emulated "
+                         "link time without traffic (sleep:GBs -- per link and direction)")
+    ap.add_argument("--lane-skip", type=int, default=0, help="streams created (and kept) before the exchange lane's: moves the lane to another hardware queue")
     a = ap.parse_args()
     if a.transport == "rccl":
         import torch.distributed as dist
@@ -152,6 +165,13 @@ def main():
     t_gen = time.time() - t0
     t0 = time.time()
     comm = LoopbackComm(P, r, degrees, a.transport)
+    if a.transport.startswith("sleep"):
+        comm.link_GBs = float(a.transport.split(":")[1])
+        torch.cuda._sleep(1000); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+        comm.spin_per_s = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+    _skipped = [torch.cuda.Stream(dev) for _ in range(a.lane_skip)]
     sg = SimGraph(idx, vals, bounds, comm=comm, cover=a.cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True)
     sg.entries = None
     del idx, vals, comm.mirrored
@@ -192,7 +212,7 @@ def main():
     st = sg.stats
     halo_rows = st["pull_rows"] + st["push_rows"]
     out = {"world": P, "rank": r, "graph": {"nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
-           "split_rows": bool(sg.split_rows), "early_pull": a.early_pull, "transport": a.transport}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
+           "split_rows": bool(sg.split_rows), "early_pull": a.early_pull, "transport": a.transport, "lane_skip": a.lane_skip}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
            "local_entries": sg.nnz_local, "push_graph_entries": (sg.push_graph.nnz if sg.push_graph is not None else 0), "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
            "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
            "kernels_breakdown_ms": breakdown, "loopback_copy_ms_per_iteration": t_x * 1e3, "step_ms_K10_loopback": t_step * 1e3,
