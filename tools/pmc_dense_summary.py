@@ -1,15 +1,16 @@
 """Per-kernel averages of a rocprofv3 --pmc run of the dense kernels (counter_collection.csv + kernel_trace.csv in one directory tree)."""
 import csv, collections, glob, sys
 root = sys.argv[1]
+pat = sys.argv[2] if len(sys.argv) > 2 else "dense"
 cc = glob.glob(root + "/**/*_counter_collection.csv", recursive=True)[0]
 kt = glob.glob(root + "/**/*_kernel_trace.csv", recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(cc)):
-    if "dense" in r["Kernel_Name"]:
+    if pat in r["Kernel_Name"]:
         agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(kt)):
-    if "dense" in r["Kernel_Name"]:
+    if pat in r["Kernel_Name"]:
         dur[r["Kernel_Name"][:70]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 for k, v in agg.items():
     d = sorted(dur[k]); ms = d[len(d) // 2]
