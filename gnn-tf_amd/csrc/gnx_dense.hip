@@ -38,6 +38,7 @@ struct DenseArgs {
     const int32_t *out_rows;      // optional: result row r goes to out[out_rows[r]]
     const int32_t *in_rows;       // optional: input row r is X[in_rows[r]]
     bool w_aligned;               // W rows start 16-byte aligned (ldw % 4 == 0, aligned base): float4 loads of W
+    const float *zeros = nullptr; // 16 bytes of device zeros (k_dense_wreg with padded widths stages them for the columns past F)
 };
 
 template <int NT> struct DenseCfg {
@@ -322,7 +323,9 @@ int launch_ring(const DenseArgs &p, hipStream_t s) {
 //     4 (RING - 2) vector-memory operations" is the wait for every stage (stores in between only make it stricter).
 // Same k order as the other two kernels: same bits.  Measured (10M x 256 -> 64, profiles/NOTES.md): the ring depth does not matter from
 // 4 stages up and the staging waits are never taken -- what the launch costs beyond the MFMAs is issue slots and the clock.
-template <int NT, int KS, int RING, bool RELU>
+// PAD: F < 64 KS and / or O < 16 NT (both multiples of 4): the columns of X past F are staged from a block of zeros (times the zero rows
+// W gets there: exact, whatever X holds), the columns past O are neither loaded from W nor stored.
+template <int NT, int KS, int RING, bool RELU, bool PAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dense_wreg(const DenseArgs p, int64_t n_tiles64) {
     constexpr int STAGE = 16 * RING_BK;
     extern __shared__ float lds[];                                // [4 waves][RING][STAGE]
@@ -341,16 +344,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                 {
-                    wreg[kc][T][t][nt] = p.W[(int64_t)(64 * kc + 16 * T + 4 * g + t) * p.ldw + 16 * nt + c];
+                    const int k = 64 * kc + 16 * T + 4 * g + t, col = 16 * nt + c;
+                    wreg[kc][T][t][nt] = (!PAD || (k < p.F && col < p.O)) ? p.W[(int64_t)k * p.ldw + col] : 0.f;
                     asm volatile("" : "+a"(wreg[kc][T][t][nt]));      // W lives in the accumulation half of the register file; the MFMAs read it there
                 }
     f32x4 bias[NT];                                               // columns 16 nt + 4 g .. + 3
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bias[nt][r] = p.bias ? p.bias[16 * nt + 4 * g + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bias[nt][r] = (p.bias && (!PAD || 16 * nt + 4 * g + r < p.O)) ? p.bias[16 * nt + 4 * g + r] : 0.f;
 
     const uint32_t n_tiles = (uint32_t)n_tiles64, n_rows = (uint32_t)p.n;
+    const uint32_t f_pieces = (uint32_t)p.F / 4;
     const uint32_t tile_stride = gridDim.x * 4, first = blockIdx.x * 4 + wave;
     const uint32_t x_pitch = (uint32_t)p.ldx * 4u, o_pitch = (uint32_t)p.ldo * 4u;      // bytes
     const char *__restrict__ Xb = reinterpret_cast<const char *>(p.X);
@@ -366,6 +371,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             uint32_t row = t16 + 4 * i + g;
             row = row < n_rows ? row : n_rows - 1;                // rows past the end read a valid row and are not stored
             const char *src = Xb + (uint64_t)row * x_pitch + (uint32_t)(pf_kc * RING_BK * 4) + piece[i];
+            if constexpr (PAD) {
+                if ((uint32_t)(pf_kc * (RING_BK / 4)) + piece[i] / 16u >= f_pieces) src = reinterpret_cast<const char *>(p.zeros);
+            }
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(src), ring + slot * STAGE + i * 256, 16, 0, 0);
         }
         if (pf_kc == KS - 1) pf_tile += tile_stride;
@@ -387,14 +395,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto store_tile = [&](f32x4 (&acc)[NT], uint32_t tile) {      // a full tile: no guards
         char *o = Ob + (uint64_t)(tile * 16u + c) * o_pitch + 16u * g;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(o + 64 * nt) = finish(acc[nt], nt);
+        for (int nt = 0; nt < NT; ++nt)
+            if (!PAD || 16 * nt + 4 * g < p.O) *reinterpret_cast<f32x4 *>(o + 64 * nt) = finish(acc[nt], nt);
     };
     auto store_last = [&](f32x4 (&acc)[NT], uint32_t tile) {      // the wave's last tile: may be the ragged one
         const uint32_t row = tile * 16u + c;
         if (row < n_rows) {
             char *o = Ob + (uint64_t)row * o_pitch + 16u * g;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4 *>(o + 64 * nt) = finish(acc[nt], nt);
+            for (int nt = 0; nt < NT; ++nt)
+                if (!PAD || 16 * nt + 4 * g < p.O) *reinterpret_cast<f32x4 *>(o + 64 * nt) = finish(acc[nt], nt);
         }
     };
     f32x4 afrag[2][4];                                            // the X fragments of the stage being multiplied and of the next one
@@ -454,19 +464,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // nothing of this wave may still be writing LDS when the block retires
 }
 
-// registers for W: (F / 4) x NT fragments per lane, at most 256 of the wave's 512
-bool wreg_eligible(const DenseArgs &p, bool x_aligned, int nt) {
+// registers for W: 16 KS x NT fragments per lane (F <= 64 KS, O <= 16 NT), at most 256 of the wave's 512; widths multiples of 4
+bool wreg_eligible(const DenseArgs &p, bool x_aligned) {
     const bool out_aligned = reinterpret_cast<uintptr_t>(p.out) % 16 == 0 && p.ldo % 4 == 0;
-    return x_aligned && out_aligned && p.in_rows == nullptr && p.out_rows == nullptr && p.F % RING_BK == 0 && (p.F / 4) * nt <= 256 && p.O == 16 * nt &&
+    return x_aligned && out_aligned && p.in_rows == nullptr && p.out_rows == nullptr && p.F % 4 == 0 && p.O % 4 == 0 && p.F > 64 && p.F <= 256 &&
            p.n >= 16 * 1024 && p.n < (1ll << 31) && p.ldx < (1ll << 30) && p.ldo < (1ll << 30);
 }
 
-template <int NT, int KS, int RING, bool RELU>
+// sixteen bytes of zeros on the device (per process: one process per GPU)
+const float *device_zeros() {
+    static float *z = nullptr;
+    if (!z) {
+        if (hipMalloc((void **)&z, 256) != hipSuccess) { z = nullptr; return nullptr; }
+        if (hipMemset(z, 0, 256) != hipSuccess) { (void)hipFree(z); z = nullptr; return nullptr; }
+    }
+    return z;
+}
+
+template <int NT, int KS, int RING, bool RELU, bool PAD>
 int launch_wreg_as(const DenseArgs &p, hipStream_t s) {
     const size_t lds_bytes = (size_t)4 * RING * 16 * RING_BK * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_wreg<NT, KS, RING, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_wreg<NT, KS, RING, RELU, PAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
         configured = true;
     }
     const int64_t n_tiles = (p.n + 15) / 16;
@@ -474,13 +494,20 @@ int launch_wreg_as(const DenseArgs &p, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)std::min<int64_t>((n_tiles + 3) / 4, cus);
-    hipLaunchKernelGGL((k_dense_wreg<NT, KS, RING, RELU>), dim3(grid), dim3(256), lds_bytes, s, p, n_tiles);
+    hipLaunchKernelGGL((k_dense_wreg<NT, KS, RING, RELU, PAD>), dim3(grid), dim3(256), lds_bytes, s, p, n_tiles);
     return GNX_OK;
 }
 
 template <int NT, int KS, int RING>
-int launch_wreg(const DenseArgs &p, hipStream_t s) {
-    return p.act == GNX_ACT_RELU ? launch_wreg_as<NT, KS, RING, true>(p, s) : launch_wreg_as<NT, KS, RING, false>(p, s);
+int launch_wreg(const DenseArgs &p0, hipStream_t s) {
+    DenseArgs p = p0;
+    const bool pad = p.F != 64 * KS || p.O != 16 * NT;
+    if (pad) {
+        p.zeros = device_zeros();
+        if (!p.zeros) return GNX_ERR_ALLOC;
+        return p.act == GNX_ACT_RELU ? launch_wreg_as<NT, KS, RING, true, true>(p, s) : launch_wreg_as<NT, KS, RING, false, true>(p, s);
+    }
+    return p.act == GNX_ACT_RELU ? launch_wreg_as<NT, KS, RING, true, false>(p, s) : launch_wreg_as<NT, KS, RING, false, false>(p, s);
 }
 
 template <int NT>
@@ -969,13 +996,13 @@ int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W
         q.O = (int)(O - o0 < 256 ? O - o0 : 256);
         const int nt = (q.O + 15) / 16;
         const int nt4 = nt;                                                // the ring kernel takes accumulator columns in whole groups of four
-        if (wreg_enabled() && wreg_eligible(q, al, nt)) {                 // shapes whose W fits the registers: (F / 4) x nt <= 256 fragments
-            int rc = -1;
-            if (q.F == 256 && nt == 4)      rc = launch_wreg<4, 4, 8>(q, s);
-            else if (q.F == 256 && nt == 2) rc = launch_wreg<2, 4, 8>(q, s);
-            else if (q.F == 128 && nt == 4) rc = launch_wreg<4, 2, 4>(q, s);
-            else if (q.F == 128 && nt == 8) rc = launch_wreg<8, 2, 4>(q, s);
-            if (rc > 0) return rc;
+        if (wreg_enabled() && wreg_eligible(q, al)) {                     // shapes whose W fits the registers (padded to 128 / 256 x 32 / 64 / 128)
+            int rc = 1;                                                       // (> 0: no shape of this kernel)
+            if (q.F > 128 && q.O <= 32)       rc = launch_wreg<2, 4, 8>(q, s);
+            else if (q.F > 128 && q.O <= 64)  rc = launch_wreg<4, 4, 8>(q, s);
+            else if (q.F <= 128 && q.O <= 64) rc = launch_wreg<4, 2, 4>(q, s);
+            else if (q.F <= 128 && q.O <= 128) rc = launch_wreg<8, 2, 4>(q, s);
+            if (rc < 0) return rc;
             if (rc == GNX_OK) continue;
         }
         if (ring_enabled() && nt % 4 == 0 && ring_eligible(q, al, nt4) && nt4 <= 16) {

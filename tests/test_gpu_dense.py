@@ -43,6 +43,8 @@ def test_dense_mfma_matches_float64(gnntf, n, F, O, relu):
 @pytest.mark.parametrize("n,F,O", [
     # W in registers (k_dense_wreg): (F / 4) x (O / 16) <= 256 fragments per lane, O a multiple of 16
     (20001, 256, 64), (16400, 256, 32), (33007, 128, 64), (17000, 128, 128), (1_000_003, 256, 64),
+    # ... with padded widths (multiples of 4): columns of X past F staged from zeros, columns past O neither loaded nor stored
+    (20003, 100, 64), (16385, 200, 40), (30000, 68, 128), (17001, 252, 4), (16500, 132, 100),
     # X through the LDS-DMA ring with W in LDS (k_dense_ring): the other tall shapes with whole 64-float K chunks
     (20001, 256, 128), (16385, 64, 64), (16400, 192, 256)])
 @pytest.mark.parametrize("relu,with_bias", [(False, True), (True, True), (True, False)])
