@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="column chunks whose exchange and SpMM overlap (0 = auto: 1, 2 and 4 are tried)")
     ap.add_argument("--early-pull", choices=["auto", "on", "off"], default="auto",
                     help="send the pulled rows ahead of the pushed partial sums (two messages per peer); auto = tried both ways")
+    ap.add_argument("--select-seconds", type=float, default=120.0,
+                    help="N > 1: wall-clock budget of the variant selection before the timed region; what does not fit is recorded as skipped")
+    ap.add_argument("--overlap-probe", choices=["on", "off"], default="on",
+                    help="N > 1: probe where the exchange runs beside the compute stream (Comm.tune_overlap; GNX_TUNE_OVERLAP=0 also disables it)")
     ap.add_argument("--whole-rows", action="store_true", help="do not split interior / boundary rows")
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
@@ -69,6 +73,24 @@ def alg_bytes_per_iteration(n, nnz, C):
 def min_bytes_per_iteration(n, nnz, C):
     """compulsory bytes, every array touched once: 8 nnz + 4 N + 12 N C."""
     return 8 * nnz + 4 * n + 12 * n * C
+
+
+def alg_bytes_dropped_iteration(n, nnz, kept, C, backward=False):
+    """One TRAINING iteration (layered.py:47-50 + gnn.py:37-42 + filter.py:19-21; gnx_spmm_dropped(_chained)) in the convention of
+    alg_bytes_per_iteration: every stored entry's column index and RAW value are read (the draw needs them), only the ``kept``
+    entries gather a neighbour row.  Forward (chained, k >= 1): + per row rowptr, D[row], the next iteration's scale, H0 and out.
+    Backward (transposed structure, no mix term): + 4 bytes per kept entry for its column's scale, per row rowptr, D[row] and out."""
+    if backward:
+        return nnz * 8 + kept * (4 * C + 4) + n * (4 + 4 + 4 * C)
+    return nnz * 8 + kept * 4 * C + n * (4 + 4 + 4 + 8 * C)
+
+
+def kept_entries(g, p, seed, first_stream, n_streams):
+    """Stored entries that survive the edge dropout of each of ``n_streams`` consecutive dropout streams (counted from the
+    materialised values, gnx_graph_normalize: a dropped entry is an explicit zero there)."""
+    import gnntf
+    return [int((gnntf.normalize(g, "symmetric", "none", dropout=p, seed=seed, stream_id=first_stream + k).vals != 0).sum())
+            for k in range(n_streams)]
 
 
 def workload_name(n, nnz, C):
@@ -167,20 +189,35 @@ def pmc_traffic(name):
 MEASURED_READ_PEAK = [None]        # in-run read-only streaming rate (set once by main)
 
 
-def roofline_record(n, nnz, C, launch_s, K, name, measured_peak):
-    """achieved = min(B_alg, B_rocprof) / t per launch; B_alg, B_min, B_rocprof and t printed together."""
-    b_alg, b_min = alg_bytes_per_iteration(n, nnz, C), min_bytes_per_iteration(n, nnz, C)
+def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_min=None, what=None):
+    """achieved = min(B_alg, B_rocprof) / t per launch; B_alg, B_min, B_rocprof and t printed together.
+    Without a committed PMC entry for ``name`` the min() cannot be taken: ``achieved`` / ``frac`` are then null
+    (``min_rule_applied`` false) and only an upper bound is given -- B_alg / t capped at the in-run read-only stream rate -- so that
+    no line can carry a fraction the counters have not bounded (or one above 1)."""
+    if b_alg is None:
+        b_alg, b_min = alg_bytes_per_iteration(n, nnz, C), min_bytes_per_iteration(n, nnz, C)
     traffic, source = pmc_traffic(name)
-    counted = min(b_alg, traffic) if traffic else b_alg
-    achieved = counted / launch_s / 1e9
-    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": traffic, "traffic_source": source, "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
+    read_peak = MEASURED_READ_PEAK[0]
+    stale = False
+    if traffic:
+        achieved = min(b_alg, traffic) / launch_s / 1e9
+        frac = achieved / HBM_PEAK_GBS
+        if frac > 1.0:            # more bytes per second than the memory system moves: the committed counters cannot belong to this launch
+            achieved, frac, stale = None, None, True
+    else:
+        achieved = frac = None
+    bound = min(b_alg / launch_s / 1e9, read_peak if read_peak else HBM_PEAK_GBS)
+    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+           "traffic": traffic, "traffic_source": source, "min_rule_applied": bool(traffic) and not stale, "traffic_entry_inconsistent_with_this_run": stale,
+           "frac_upper_bound": min(bound / HBM_PEAK_GBS, 1.0),
+           "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
            "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K,
-           "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if measured_peak else None,
-           "measured_read_peak": MEASURED_READ_PEAK[0],
-           "frac_of_measured_read_peak": (achieved / MEASURED_READ_PEAK[0]) if MEASURED_READ_PEAK[0] else None,
-           "note": "one launch = one fused SpMM+mix iteration incl. its long-row kernels; achieved = min(B_alg, traffic) / launch time; "
-                   "traffic = bytes leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE): Infinity-Cache hits are counted in it, so this is a "
+           "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if (measured_peak and achieved) else None,
+           "measured_read_peak": read_peak,
+           "frac_of_measured_read_peak": (achieved / read_peak) if (read_peak and achieved) else None,
+           "note": (what or "one launch = one fused SpMM+mix iteration incl. its long-row kernels") + "; achieved = min(B_alg, traffic) / launch time "
+                   "(null when no PMC entry exists for this workload: frac_upper_bound = min(B_alg / t, in-run read-only stream) / peak is then all "
+                   "that can be said); traffic = bytes leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE): Infinity-Cache hits are counted in it, so this is a "
                    "fabric-level figure, not DRAM bandwidth; measured_peak = in-run device stream copy (read + write), measured_read_peak = in-run "
                    "read-only stream (the SpMM is almost all reads)"}
     return rec
@@ -332,7 +369,34 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
                         "what": f"gnntf.APPNP(graph, X[N, {F}], num_classes={C}, latent_dims=[]) in eval mode: predict_ms = architecture.predict(NodeClassification("
                                 f"100k nodes)) with the memo cleared (Dense {F} -> {C} on the matrix cores + K = {K} propagation + gather/argmax); "
                                 f"ppr_loop_layer_ms = the PPRLoop layer's forward alone; gnx_appnp_propagate_ms = the C entry on the same H0"})
-        del model, X, H0, res, work, task, nodes, loop
+        del model, H0, res, work, task, nodes, loop
+        torch.cuda.empty_cache()
+        # the same propagation as user code builds it (reference demos/custom_layers.py:8-13): a Dense and K hand-added
+        # PPRIteration(H0, a) layers.  The container runs them as one fused loop (Layer.__run__); fuse_runs = False is the
+        # layer-by-layer execution of the same stack (K launches, K intermediate values)
+        gnntf.set_seed(0)
+        hand = gnntf.GNN(g, X)
+        H0l = hand.add(gnntf.Dense(C, regularize=False))
+        for _ in range(K):
+            hand.add(gnntf.PPRIteration(H0l, a))
+        hand.training_mode(False)
+        with torch.no_grad():
+            t_hand = median_ms(lambda: hand(hand.features), reps=3, warm=1)
+            t_dense = median_ms(lambda: H0l(hand, hand.features), reps=3, warm=1)
+            fused_out = hand(hand.features)
+            hand.fuse_runs = False
+            t_hand_layers = median_ms(lambda: hand(hand.features), reps=3, warm=1)
+            by_layer = hand(hand.features)
+            for layer in hand.layers():
+                layer.value = None
+        via_api[-1]["hand_built_stack"] = {"layers": [type(l).__name__ for l in hand.layers()][:3] + ["..."], "forward_ms": t_hand,
+                                           "dense_alone_ms": t_dense, "propagation_ms": t_hand - t_dense,
+                                           "layer_by_layer_forward_ms": t_hand_layers,
+                                           "max_abs_difference_to_layer_by_layer": float((fused_out - by_layer).abs().max()),
+                                           "what": f"GNN(graph, X) + Dense({C}) + {K} x PPRIteration(H0, {a}) added by hand, eval mode: forward_ms with the "
+                                                   f"container fusing the run (propagation_ms = forward - the Dense alone: to be compared with "
+                                                   f"ppr_loop_layer_ms), layer_by_layer_forward_ms with fuse_runs = False"}
+        del hand, H0l, X, fused_out, by_layer
         torch.cuda.empty_cache()
     out["config4_via_layer_api"] = via_api
     # training-mode step: K = 10 iterations, each with its own dropped + re-normalised adjacency,
@@ -350,11 +414,35 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         gnntf.ppr_loop(make, H0, a, K).backward(gout)
     ms = median_ms(lambda: train_step(None), reps=3, warm=1)
     ms2 = median_ms(lambda: train_step(two_pass), reps=3, warm=1)
+    # the two launches the step consists of, each timed alone with events and priced against its own byte model (one forward
+    # iteration k >= 1 = gnx_spmm_dropped_chained; one backward iteration = gnx_spmm_dropped on the transposed structure)
+    from gnntf import sparse as sp
+    kept = kept_entries(g, 0.5, 1, 1, 1)[0]
+    scales = sp.dropped_degree_scales(g, 0.5, 1, 0, K)
+    adj1 = sp.dropped_adjacency(g, 0.5, 1, 1, D=scales[1])
+    Xd = H0.detach()
+    with torch.no_grad():
+        ms_f = median_ms(lambda: sp._launch_chained(adj1, Xd, Xd, 1.0 - a, a, True, scales[2]), reps=5, warm=2)
+        kernel_f = g.last_kernel()
+        ms_b = median_ms(lambda: sp._launch(adj1, gout, None, 1.0 - a, 0.0, nat.ACT_NONE, transposed=True), reps=5, warm=2)
+        ms_d = median_ms(lambda: sp.dropped_degree_scales(g, 0.5, 1, 0, K), reps=3, warm=1)
+    wl = workload_name(n4, e4, C)
+    roof_f = roofline_record(n, nnz, C, ms_f * 1e-3, K, "train_forward_" + wl, measured_peak,
+                             b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C), what="one forward TRAINING iteration (gnx_spmm_dropped_chained, "
+                             "k >= 1: weights from the counter RNG inside the SpMM, only kept entries gathered) incl. its long-row kernels")
+    roof_b = roofline_record(n, nnz, C, ms_b * 1e-3, K, "train_backward_" + wl, measured_peak,
+                             b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True), what="one backward TRAINING iteration "
+                             "(gnx_spmm_dropped over the transposed structure, the column scale gathered per kept entry) incl. its long-row kernels")
     out["training_step_C64"] = {"ms": ms, "two_pass_ms": ms2, "edges_per_s": 2 * nnz * K / ms * 1e3,
+                                "forward_launch_ms": ms_f, "backward_launch_ms": ms_b, "degree_scales_all_streams_ms": ms_d,
+                                "launches_share_of_step": (K * (ms_f + ms_b) + ms_d) / ms, "kept_entries": kept, "kernel": kernel_f,
+                                "roofline": roof_f, "roofline_backward": roof_b,
                                 "what": f"forward + backward of {K} PPR iterations with per-iteration edge dropout 0.5 + renormalisation, "
                                         f"config-4 graph, C=64; ms: weights produced inside the SpMM (gnx_spmm_dropped), two_pass_ms: "
-                                        f"materialised per iteration (gnx_graph_normalize + gnx_spmm)"}
-    del H0, gout
+                                        f"materialised per iteration (gnx_graph_normalize + gnx_spmm); roofline / roofline_backward: one "
+                                        f"forward / backward iteration's launch timed alone, byte model alg_bytes_dropped_iteration (col + raw "
+                                        f"value of EVERY entry, a neighbour row per KEPT entry, H0 + out + scales per row)"}
+    del H0, gout, Xd, scales, adj1
     torch.cuda.empty_cache()
     # the matrix-core ends of the path at the config-4 size
     mf = {}
@@ -467,6 +555,11 @@ def note(msg):
 
 
 T_START = time.time()
+PHASES = {}                        # seconds per phase of the run (rank 0's clock), printed in config.phases
+
+
+def phase(name, t0):
+    PHASES[name] = round(PHASES.get(name, 0.0) + time.time() - t0, 2)
 
 
 def main():
@@ -511,6 +604,8 @@ def main():
 
     if not sharded_path:
         g, adj, prep = build_single(args, device)
+        PHASES["startup"] = round(time.time() - T_START - prep["gen_s"] - prep["prep_s"], 2)
+        PHASES.update(generate=prep["gen_s"], prep=prep["prep_s"])
         n_local, nnz_local, nnz_global = g.n_rows, g.nnz, g.nnz
         note(f"graph built: {g.n_rows} rows / {g.nnz} entries, prep {prep}")
         gen = torch.Generator(device=device).manual_seed(2)
@@ -539,6 +634,8 @@ def main():
     else:
         from gnntf import rmat, sharded
         idx, vals, bounds, comm, (gv, gf, pv, pf), t_gen = rmat.rmat_block_entries(args.nodes, args.entries, seed=1, device=device, grid=(pv, pf))
+        PHASES["startup_and_process_group"] = round(time.time() - T_START - t_gen, 2)
+        PHASES["generate_and_broadcast"] = round(t_gen, 2)
         C_local = C // pf                                                       # this rank's feature slice
         gen = torch.Generator(device=device).manual_seed(2 + rank)
         # Which halo plan / pipelining is fastest depends on what the links of THIS node sustain, which nothing on a one-GPU box
@@ -549,16 +646,23 @@ def main():
         if pv == 1:
             covers = covers[:1]                                                 # one vertex block: nothing is exchanged
         chunk_options = [k for k in (1, 2, 4) if k <= max(C_local // 32, 1)] if args.chunks <= 0 else [args.chunks]
-        t0 = time.time()
-        graphs = {cover: sharded.ShardedGraph(idx, vals, bounds, comm=comm, cover=cover, chunks=chunk_options[-1],
-                                              split_rows=not args.whole_rows, relabel=True) for cover in covers}
-        del idx, vals
-        torch.cuda.synchronize()
-        torch.cuda.empty_cache()
-        prep = dict(gen_s=round(t_gen, 2), prep_s=round(time.time() - t0, 2), plans_built=covers)
+        # most promising first (two chunks overlap exchange and SpMM at the least extra launches), so that a selection cut short by
+        # its wall-clock budget (--select-seconds) has timed the likely winners
+        chunk_order = [k for k in (2, 4, 1) if k in chunk_options] or chunk_options
+        graphs, plan_s = {}, {}
+
+        def build_plan(cover):
+            t0 = time.time()
+            graphs[cover] = sharded.ShardedGraph(idx, vals, bounds, comm=comm, cover=cover, chunks=chunk_options[-1],
+                                                 split_rows=not args.whole_rows, relabel=True, tune_overlap=args.overlap_probe == "on")
+            torch.cuda.synchronize()
+            plan_s[cover] = round(time.time() - t0, 2)
+
+        build_plan(covers[0])
         sg = graphs[covers[0]]
         n_local, nnz_local, nnz_global = sg.n_local, sg.nnz_local, sg.nnz_global
-        note(f"vertex blocks built: {pv} x {pf} grid, {n_local} rows / {nnz_local} entries on rank 0, prep {prep}")
+        PHASES["plan_" + covers[0]] = plan_s[covers[0]]
+        note(f"vertex blocks built ({covers[0]}): {pv} x {pf} grid, {n_local} rows / {nnz_local} entries on rank 0, {plan_s[covers[0]]} s")
         H0 = torch.rand(n_local, C_local, device=device, generator=gen) * 2 - 1
 
         def rank_max_ms(fn, reps=2):
@@ -574,13 +678,36 @@ def main():
                 best = float(t.item()) if best is None else min(best, float(t.item()))
             return best * 1e3
 
-        variants = []
-        if sg.world > 1 and (len(covers) > 1 or len(chunk_options) > 1 or args.early_pull == "auto"):
+        t_select = time.perf_counter()
+
+        def select_spent():
+            """Seconds since the selection began on the SLOWEST rank: every rank sees the same number and takes the same branch."""
+            t = torch.tensor([time.perf_counter() - t_select], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        variants, skipped = [], []
+        selecting = sg.world > 1 and (len(covers) > 1 or len(chunk_options) > 1 or args.early_pull == "auto")
+        if selecting:
+            budget = float(args.select_seconds)
             for cover in covers:
+                if cover not in graphs:
+                    # a second plan costs what the first one did: it is built only if that still fits the budget
+                    spent = select_spent()
+                    if spent + plan_s[covers[0]] > budget:
+                        skipped.append(dict(cover=cover, reason=f"plan not built: {spent:.1f} s of the {budget:.0f} s selection budget spent, a plan takes {plan_s[covers[0]]} s"))
+                        note(f"selection budget: the {cover} plan is not built")
+                        continue
+                    build_plan(cover)
+                    PHASES["plan_" + cover] = plan_s[cover]
                 cand = graphs[cover]
                 earlies = [False, True] if (args.early_pull == "auto" and cand.n_send_push_max > 0 and cand.n_send_pull_max > 0) \
                     else [args.early_pull == "on"]
-                for chunks in chunk_options:
+                for chunks in chunk_order:
+                    have_one = any(v["step_ms"] is not None for v in variants)
+                    if have_one and select_spent() > budget:
+                        skipped.append(dict(cover=cover, chunks=chunks, reason="selection budget spent"))
+                        continue
                     # a variant that cannot be set up on SOME rank (memory) is dropped on EVERY rank: the decision is collective
                     state, problem = None, ""
                     try:
@@ -594,8 +721,11 @@ def main():
                         state = None
                         torch.cuda.empty_cache()
                         continue
-                    alone = dict(exchange_ms_alone=cand.time_exchange(state, repeats=2) * 1e3, compute_ms_alone=cand.time_compute(state, a, repeats=2) * 1e3)
+                    alone = dict(exchange_ms_alone=cand.time_exchange(state, repeats=1) * 1e3, compute_ms_alone=cand.time_compute(state, a, repeats=1) * 1e3)
                     for early in earlies:
+                        if any(v["step_ms"] is not None for v in variants) and select_spent() > budget:
+                            skipped.append(dict(cover=cover, chunks=chunks, early_pull=early, reason="selection budget spent"))
+                            continue
                         run = lambda: cand.propagate(state, a, K, early_pull=early)
                         run()                                                   # opens the connections / sizes the scratch of this variant
                         variants.append(dict(cover=cover, chunks=chunks, early_pull=early, step_ms=rank_max_ms(run), **alone))
@@ -606,10 +736,14 @@ def main():
             if not timed:
                 raise SystemExit("bench.py: no halo variant could be set up")
             best = min(timed, key=lambda v: v["step_ms"])                        # the same numbers on every rank: the same choice
+            PHASES["variant_selection"] = round(time.perf_counter() - t_select, 2)
         else:
             best = dict(cover=covers[0], chunks=chunk_options[-1] if args.chunks <= 0 else args.chunks, early_pull=args.early_pull == "on")
+        del idx, vals
+        torch.cuda.empty_cache()
+        prep = dict(gen_s=round(t_gen, 2), prep_s=round(sum(plan_s.values()), 2), plans_built=list(graphs), plan_s=plan_s)
         sg = graphs[best["cover"]]
-        for cover in covers:
+        for cover in list(graphs):
             if cover != best["cover"]:
                 del graphs[cover]
         torch.cuda.empty_cache()
@@ -619,7 +753,8 @@ def main():
             sg.propagate(state, a, K, early_pull=best["early_pull"])
         halo = sg.halo_stats()
         halo.update(chunks=best["chunks"], early_pull=best["early_pull"], variants_timed_before_the_run=variants,
-                    overlap_probe=getattr(sg.comm, "overlap_probe", None),
+                    variants_skipped=skipped, select_seconds_budget=args.select_seconds if selecting else None,
+                    overlap_probe=getattr(sg.comm, "overlap_probe", None), overlap_probe_status=getattr(sg.comm, "overlap_status", None),
                     chosen=dict(best), pull_rows_sent=sg.n_send_pull_max, push_rows_sent=sg.n_send_push_max)
 
     def barrier():
@@ -628,14 +763,18 @@ def main():
         torch.cuda.synchronize()
 
     note(f"timing {args.warmup} + {args.steps} steps")
+    t_ph = time.time()
     elapsed, step_ms = timed_steps(step, args.steps, args.warmup, barrier)
+    phase("warmup_and_timed_steps", t_ph)
     note(f"steps done: {elapsed / args.steps * 1e3:.1f} ms per step on this rank")
     if sharded_path:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if world > 1:                        # measured, per iteration: the bare exchange and the bare kernels (collective calls)
+            t_ph = time.time()
             t_x, t_c = sg.time_exchange(state), sg.time_compute(state, a)
+            phase("exchange_and_kernels_alone", t_ph)
             halo_bytes = halo["max_halo_rows"] * C_local * 4
             halo.update(exchange_ms_alone=t_x * 1e3, compute_ms_alone=t_c * 1e3, halo_bytes_per_rank_per_iteration=halo_bytes,
                         ingress_GBs_per_rank=halo_bytes / max(t_x, 1e-9) / 1e9,
@@ -645,6 +784,7 @@ def main():
     # in-run parity evidence: sqrt(degree) x s is a fixed point of the propagation on a symmetric graph -- K more iterations through
     # the very path that was timed (for N > 1: the plan, the kernels AND the RCCL exchange) must reproduce it
     note("self check: fixed point of the propagation")
+    t_ph = time.time()
     if sharded_path:
         check_err = sg.fixed_point_error(state, a, K)
     else:
@@ -673,6 +813,7 @@ def main():
                           "after K iterations through the timed path, relative to max(|H0|, 1), max over ranks",
                   "max_rel_err": check_err, "ok": bool(check_err < 1e-4)}
     note(f"self check: {check_err:.2e}")
+    phase("self_check", t_ph)
 
     # N > 1, second field (never the headline): the SAME graph replicated on every rank, each rank propagating C / N of the feature
     # columns -- no exchange at all, graph memory and prep grow with N.  Tells how far the vertex blocks are from a link-free bound.
@@ -681,6 +822,7 @@ def main():
         note(f"exchange alone {halo['exchange_ms_alone']:.2f} ms, kernels alone {halo['compute_ms_alone']:.2f} ms per iteration")
     if world > 1 and not args.no_alt_grid and not args.grid and C % world == 0:
         note("second field: the whole graph on every rank, C / N columns each")
+        t_ph = time.time()
         kernel_blocks = sg.graph.last_kernel()
         graphs.clear()
         del state, sg, H0
@@ -715,13 +857,16 @@ def main():
                            "vertex-block grid, never instead of it"}
             del g2, adj2, H2, out2, work2
             note(f"feature slices: {alt['ms_per_step']:.1f} ms per step")
+        phase("alt_grid_feature_slices", t_ph)
     else:
         kernel_blocks = sg.graph.last_kernel() if sharded_path else None
 
     if rank == 0:
         edges = nnz_global * K * args.steps
+        t_ph = time.time()
         measured_peak = stream_copy_GBs(device)
         MEASURED_READ_PEAK[0] = stream_read_GBs(device)
+        phase("stream_yardsticks", t_ph)
         name = workload_name(args.nodes, args.entries, C)
         if not sharded_path:
             launch_s = (sum(step_ms) / len(step_ms)) / 1e3 / K      # one fused SpMM+mix launch (+ its long-row tail)
@@ -740,19 +885,24 @@ def main():
                        "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (kernel_blocks if sharded_path else g.last_kernel()),
                        "api": (None if sharded_path else api),
-                       "alt_grid_feature_slices": alt, "self_check": self_check},
+                       "alt_grid_feature_slices": alt, "self_check": self_check, "phases_s": PHASES},
             "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:
             note("CPU baselines (C / OpenMP port, scipy on one thread, torch.sparse on all threads; bounded samples)")
+            t_ph = time.time()
             result["cpu_baseline"] = cpu_baseline(g, adj, H0, args)
+            phase("cpu_baseline", t_ph)
         else:
             result["cpu_baseline"] = None
         if not sharded_path and not args.no_secondary:
             del g, adj, H0, model, loop
             torch.cuda.empty_cache()
             note("secondary workloads")
+            t_ph = time.time()
             result["secondary"] = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4")
+            phase("secondary_workloads", t_ph)
+        PHASES["total"] = round(time.time() - T_START, 2)
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     if sharded_path:
         dist.barrier()

@@ -184,6 +184,23 @@ __global__ void k_make_rkeys(const int32_t *__restrict__ rowidx, const int32_t *
     payload[k] = (int32_t)k;
 }
 
+// relabelling order inside a degree bin: key[v] = smallest degree rank among v's neighbours (its most popular neighbour)
+__global__ void k_min_neighbour_rank(const int32_t *__restrict__ rowidx, const int32_t *__restrict__ colidx, const int32_t *__restrict__ rank,
+                                     int64_t nnz, int32_t *__restrict__ key) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) atomicMin(&key[rowidx[k]], rank[colidx[k]]);
+}
+
+__global__ void k_relabel_keys(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ key, int64_t n, int clamp,
+                               uint64_t *__restrict__ keys, int32_t *__restrict__ ids) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t d = rowptr[r + 1] - rowptr[r];
+    const uint64_t bin = (uint64_t)(clamp - (d < clamp ? d : clamp));          // k_order_keys' bins: heaviest first
+    keys[r] = (bin << 32) | (uint64_t)(uint32_t)key[r];
+    ids[r] = (int32_t)r;
+}
+
 __global__ void k_permute_vals(const float *__restrict__ vals, const int32_t *__restrict__ perm, int64_t n,
                                float *__restrict__ out) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,7 +368,8 @@ static void drop_relabel(gnx_graph *g) {
     free_csr(g->r);
     if (g->r_perm) (void)hipFree(g->r_perm);
     if (g->r_vals) (void)hipFree(g->r_vals);
-    g->r_perm = nullptr; g->r_vals = nullptr;
+    if (g->r_order) (void)hipFree(g->r_order);
+    g->r_perm = nullptr; g->r_vals = nullptr; g->r_order = nullptr;
     g->has_r = false;
 }
 
@@ -364,8 +382,10 @@ int ensure_relabel_features(gnx_graph *g, size_t bytes) {
     return GNX_OK;
 }
 
-// The matrix with its vertices renumbered in the degree-binned order (heaviest first): same entries, rows and columns permuted
-// alike, columns ascending inside a row.  Built once, on the first narrow-width propagation of a large square graph.
+// The matrix with its vertices renumbered in the degree-binned order (heaviest first; inside a bin by the degree rank of a vertex's
+// most popular neighbour -- profiles/NOTES.md round 4: -4 % time, -16 % of the long-row kernel's fabric bytes at C = 8): same
+// entries, rows and columns permuted alike, columns ascending inside a row.  Built once, on the first narrow-width propagation of
+// a large square graph.
 int ensure_relabel(gnx_graph *g, hipStream_t s) {
     if (g->has_r) return GNX_OK;
     struct Undo { gnx_graph *g; ~Undo() { if (g && !g->has_r) drop_relabel(g); } } undo{g};
@@ -378,9 +398,29 @@ int ensure_relabel(gnx_graph *g, hipStream_t s) {
     GNX_HIP(hipMalloc((void **)&r.colidx, nnz * sizeof(int32_t)));
     GNX_HIP(hipMalloc((void **)&g->r_perm, nnz * sizeof(int32_t)));
     GNX_HIP(hipMalloc((void **)&g->r_vals, nnz * sizeof(float)));
+    GNX_HIP(hipMalloc((void **)&g->r_order, n * sizeof(int32_t)));
     DevBuf newid, k0, k1, p0, rrow, tmp;
     GNX_HIP(newid.alloc(n * 4)); GNX_HIP(k0.alloc(nnz * 8)); GNX_HIP(k1.alloc(nnz * 8)); GNX_HIP(p0.alloc(nnz * 4)); GNX_HIP(rrow.alloc(nnz * 4));
-    hipLaunchKernelGGL(k_invert_order, dim3(blocks_for(n)), dim3(256), 0, s, a.row_order, n, newid.as<int32_t>());
+    {   // the order: degree bins (heaviest first); inside a bin by the degree rank of the most popular neighbour, then by id
+        DevBuf key, ids, otmp;
+        GNX_HIP(key.alloc(n * 4)); GNX_HIP(ids.alloc(n * 4));
+        hipLaunchKernelGGL(k_invert_order, dim3(blocks_for(n)), dim3(256), 0, s, a.row_order, n, newid.as<int32_t>());   // degree rank
+        GNX_HIP(hipMemsetAsync(key.p, 0x7f, n * 4, s));                            // 0x7f7f7f7f: "no neighbour" sorts last
+        hipLaunchKernelGGL(k_min_neighbour_rank, dim3(blocks_for(nnz)), dim3(256), 0, s, g->rowidx, a.colidx, newid.as<int32_t>(), nnz,
+                           key.as<int32_t>());
+        const int clamp = a.long_row < 65535 ? a.long_row : 65535;                 // as build_long_plan binned the rows
+        hipLaunchKernelGGL(k_relabel_keys, dim3(blocks_for(n)), dim3(256), 0, s, a.rowptr, key.as<int32_t>(), n, clamp,
+                           k0.as<uint64_t>(), ids.as<int32_t>());
+        const unsigned order_bits = 32u + bits_for((uint64_t)clamp + 1);
+        size_t ob = 0;
+        GNX_HIP(rocprim::radix_sort_pairs(nullptr, ob, k0.as<uint64_t>(), k1.as<uint64_t>(), ids.as<int32_t>(), g->r_order, (size_t)n, 0u,
+                                          order_bits, s));
+        GNX_HIP(otmp.alloc(ob));
+        GNX_HIP(rocprim::radix_sort_pairs(otmp.p, ob, k0.as<uint64_t>(), k1.as<uint64_t>(), ids.as<int32_t>(), g->r_order, (size_t)n, 0u,
+                                          order_bits, s));
+        GNX_HIP(hipStreamSynchronize(s));
+    }
+    hipLaunchKernelGGL(k_invert_order, dim3(blocks_for(n)), dim3(256), 0, s, g->r_order, n, newid.as<int32_t>());
     hipLaunchKernelGGL(k_make_rkeys, dim3(blocks_for(nnz)), dim3(256), 0, s, g->rowidx, a.colidx, newid.as<int32_t>(), nnz, n,
                        k0.as<uint64_t>(), p0.as<int32_t>());
     const unsigned end_bit = bits_for((uint64_t)n * (uint64_t)n);
@@ -433,6 +473,7 @@ int gnx_graph_destroy(gnx_graph_t g) {
     free_csr(g->r);
     if (g->r_perm) (void)hipFree(g->r_perm);
     if (g->r_vals) (void)hipFree(g->r_vals);
+    if (g->r_order) (void)hipFree(g->r_order);
     if (g->r_feat) (void)hipFree(g->r_feat);
     delete g;
     return GNX_OK;

@@ -47,6 +47,9 @@ constexpr int LONG_CHUNK = GNX_LONG_CHUNK;
 // 2^20 rows the plan therefore cuts rows at 128 entries into 128-entry chunks, and the sub-wave kernels take chunks and short rows in one launch.
 constexpr int SMALL_ROWS = 1 << 20;
 constexpr int TINY_ROWS = 1 << 15;      // below this everything is cache-resident and launch-bound: an extra reduce launch costs more than it saves
+// widest feature rows (floats) the K loop runs on the degree-relabelled copy of a large square graph: 32 floats = one 128-byte line
+// per gather; measured round 4 (RMAT 10M / 100M, K = 10): C = 32 22.8 -> 21.2 ms with the vertices in that order, C = 64 loses
+constexpr int RELABEL_MAX_C = 32;
 constexpr int SMALL_LONG_ROW = GNX_LONG_ROW < 128 ? GNX_LONG_ROW : 128;
 
 // One CSR-like structure (the matrix itself, or its transpose).
@@ -93,10 +96,13 @@ struct gnx_graph {
     // scale of local row r sits at position blk_row0_buf + r of the per-column scale vector
     int64_t blk_row0_global = 0, blk_row0_buf = 0;
     int32_t *blk_col_gid = nullptr;            // [a.n_cols] global vertex id of every column (owned), or null
-    // degree-relabelled copy of a square matrix (lazy; narrow feature widths): vertex a.row_order[i] becomes vertex i, so the
-    // rows of the hubs -- which most gathers hit -- are neighbours in memory and share cache lines
+    // degree-relabelled copy of a square matrix (lazy; narrow feature widths): vertex r_order[i] becomes vertex i, so the
+    // rows of the hubs -- which most gathers hit -- are neighbours in memory and share cache lines.  r_order = the degree bins
+    // of a.row_order (heaviest first) and, inside a bin, the vertices by the degree rank of their most popular neighbour: the
+    // leaves of one hub become neighbours too, so the hub's row gathers them from consecutive lines
     bool has_r = false;
     gnx::Csr r;
+    int32_t *r_order = nullptr;  // [n] new id -> old id
     int32_t *r_perm = nullptr;   // [a.nnz] coalesced slot of every relabelled entry
     float *r_vals = nullptr;     // [a.nnz] scratch: values gathered into relabelled order
     float *r_feat = nullptr;     // scratch: H0 in relabelled row order

@@ -1580,7 +1580,7 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
     // four to eight of the rows that receive most gathers share a line): H0 is permuted once on the way in, the LAST iteration
     // scatters its rows straight back into the caller's order.  -16..-21 % per iteration at C = 16 / 8 (RMAT 10M / 100M); the
     // sums run over a row's columns in the relabelled order, so results agree with the plain path to float32 rounding.
-    if (C <= 16 && n >= (1 << 20) && g->a.nnz >= n && d_diag == nullptr) {
+    if (C <= RELABEL_MAX_C && n >= (1 << 20) && g->a.nnz >= n && d_diag == nullptr) {
         int rc = ensure_relabel(g, s);
         if (rc != GNX_OK) return rc;
         rc = ensure_relabel_features(g, (size_t)n * C * sizeof(float));
@@ -1588,7 +1588,7 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
         hipLaunchKernelGGL(k_gather_vals, dim3(blocks_for(g->a.nnz, 256)), dim3(256), 0, s, d_vals ? d_vals : g->raw_vals, g->r_perm, g->a.nnz,
                            g->r_vals);
         hipLaunchKernelGGL(k_gather_rows32, dim3((unsigned)std::min<int64_t>(blocks_for(n * C, 256), 1 << 22)), dim3(256), 0, s, d_H0, C,
-                           g->a.row_order, n, (int)C, g->r_feat, C);
+                           g->r_order, n, (int)C, g->r_feat, C);
         const float *src = g->r_feat;
         for (int k = 0; k < K; ++k) {
             const bool last = k == K - 1;
@@ -1597,7 +1597,7 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
             p.vals = g->r_vals; p.X = src; p.ldx = C; p.H0 = g->r_feat; p.ldh0 = C; p.beta = (float)(1.0 - (double)a); p.alpha = a;
             p.act = (k >= 2 && !last) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
             p.out = dst; p.ldo = C; p.C = (int)C;
-            p.out_rows = last ? g->a.row_order : nullptr;           // relabelled row i is the caller's row row_order[i]
+            p.out_rows = last ? g->r_order : nullptr;               // relabelled row i is the caller's row r_order[i]
             rc = launch_spmm(g, g->r, p, s);
             if (rc != GNX_OK) return rc;
             src = dst;

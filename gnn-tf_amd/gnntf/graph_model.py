@@ -93,8 +93,48 @@ class GNN(Trainable):
         return self._adjacency_cache[key]
 
 
+def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout):
+    """``iterations`` PPR steps from H0 through the fused loop (what PPRLoop and a run of plain PPRIteration layers execute).
+    Returns (result, run) with run(k) = the value after the first k iterations (for the intermediate layers' lazy ``.value``)."""
+    training = graph_dropout != 0 and architecture.is_training()
+    if training:
+        seed, first = architecture._next_mask_stream(iterations)
+        graph, p = architecture.graph, graph_dropout
+        if sparse.can_fuse_dropout(graph, p):
+            # the degree scales of all K iterations in one pass over the structure; kept (K x N floats) for the backward
+            scales = sparse.dropped_degree_scales(graph, p, seed, first, iterations)
+            make_adj = lambda k, bwd=False: sparse.dropped_adjacency(graph, p, seed, first + k, D=scales[k])
+        elif graph.nnz * iterations * 4 <= (64 << 20):
+            # small graph (launch-latency regime): keep the K materialised adjacencies for the backward (one permute launch
+            # there instead of three launches to regenerate); large graphs regenerate to save K nnz-sized arrays
+            kept = dict()
+
+            def make_adj(k, bwd=False):
+                if k not in kept:
+                    kept[k] = sparse.normalize(graph, "symmetric", "none", p, seed, first + k)
+                return kept.pop(k) if bwd else kept[k]
+        else:
+            make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
+    else:
+        adj = architecture.get_adjacency(graph_dropout)
+        make_adj = lambda k, bwd=False: adj
+    if not torch.is_grad_enabled() and not training:
+        run = lambda k: sparse.appnp_propagate(make_adj(0, False), H0_value, a, k)
+    else:
+        run = lambda k: sparse.ppr_loop(make_adj, H0_value, a, k)
+    return run(iterations), run
+
+
 class PPRIteration(Layer):
-    """One APPNP power-iteration step (filter.py:6-22): activation(dropout((A.H)(1-a) + H0 a))."""
+    """One APPNP power-iteration step (filter.py:6-22): activation(dropout((A.H)(1-a) + H0 a)).
+
+    A RUN of such layers as user code builds it (reference demos/custom_layers.py:8-13: ``for _ in range(10):
+    gnn.add(PPRIteration(H0, 0.1))``) executes as one fused loop when the layers are plain -- the same H0 layer, one float restart
+    probability, identity activation and restart transform, no feature dropout, one graph_dropout -- and the run starts from
+    H0's own value: the same arithmetic and the same sequence of edge-dropout masks as layer by layer (bitwise on graphs below
+    2^20 vertices; above, narrow widths run on the relabelled copy: float32 rounding), at the cost of the PPRLoop layer.  The last
+    layer of the run holds the result; the ``.value`` of an intermediate layer is computed when somebody reads it.
+    ``architecture.fuse_runs = False`` switches this off."""
 
     def __build__(self, architecture: GNN, H0: Layer, restart_probability: float = 0.1, activation=linear,
                   dropout: float = 0, graph_dropout: float = 0.5, restart_transform=linear):
@@ -111,6 +151,42 @@ class PPRIteration(Layer):
         a = self.restart_transform(self.restart_probability)
         mixed = sparse.ppr_step(self.G, features, self.H0.value, a)
         return self.activation(architecture.dropout(mixed, self.dropout))
+
+    # ``.value`` (layered.py:79-81) may be pending after a fused run: computed on first read
+    @property
+    def value(self):
+        pending = self.__dict__.get("_pending_value")
+        if pending is not None:
+            self.__dict__["_value"], self.__dict__["_pending_value"] = pending(), None
+        return self.__dict__.get("_value")
+
+    @value.setter
+    def value(self, v):
+        self.__dict__["_value"], self.__dict__["_pending_value"] = v, None
+
+    def _plain(self):
+        a = self.restart_probability
+        return (type(self) is PPRIteration and isinstance(a, (int, float)) and not isinstance(a, bool) and self.activation is linear
+                and self.restart_transform is linear and self.dropout == 0 and self.output_regularize == 0)
+
+    def __run__(self, architecture: GNN, features, stack, at):
+        if not self._plain() or not isinstance(architecture, GNN) or features is not getattr(self.H0, "value", None) \
+                or not isinstance(features, torch.Tensor) or not features.is_cuda:
+            return None
+        run = [self]
+        for layer in stack[at + 1:]:
+            if not (isinstance(layer, PPRIteration) and layer._plain() and layer.H0 is self.H0 and layer is not self
+                    and layer.restart_probability == self.restart_probability and layer.graph_dropout == self.graph_dropout
+                    and all(layer is not seen for seen in run)):
+                break
+            run.append(layer)
+        if len(run) < 2:
+            return None
+        out, upto = _propagation_run(architecture, features, float(self.restart_probability), len(run), self.graph_dropout)
+        for k, layer in enumerate(run[:-1]):
+            layer.__dict__["_value"], layer.__dict__["_pending_value"] = None, (lambda k=k: upto(k + 1))
+        run[-1].value = out
+        return len(run), out
 
 
 class PPRLoop(Layer):
@@ -129,30 +205,7 @@ class PPRLoop(Layer):
         return architecture.top_shape()
 
     def __forward__(self, architecture: GNN, features):
-        if self.graph_dropout != 0 and architecture.is_training():
-            seed, first = architecture._next_mask_stream(self.iterations)
-            graph, p = architecture.graph, self.graph_dropout
-            if sparse.can_fuse_dropout(graph, p):
-                # the degree scales of all K iterations in one pass over the structure; kept (K x N floats) for the backward
-                scales = sparse.dropped_degree_scales(graph, p, seed, first, self.iterations)
-                make_adj = lambda k, bwd=False: sparse.dropped_adjacency(graph, p, seed, first + k, D=scales[k])
-            elif graph.nnz * self.iterations * 4 <= (64 << 20):
-                # small graph (launch-latency regime): keep the K materialised adjacencies for the backward (one permute launch
-                # there instead of three launches to regenerate); large graphs regenerate to save K nnz-sized arrays
-                kept = dict()
-
-                def make_adj(k, bwd=False):
-                    if k not in kept:
-                        kept[k] = sparse.normalize(graph, "symmetric", "none", p, seed, first + k)
-                    return kept.pop(k) if bwd else kept[k]
-            else:
-                make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
-        else:
-            adj = architecture.get_adjacency(self.graph_dropout)
-            make_adj = lambda k, bwd=False: adj
-        if not torch.is_grad_enabled() and not (self.graph_dropout != 0 and architecture.is_training()):
-            return sparse.appnp_propagate(make_adj(0, False), self.H0.value, self.restart_probability, self.iterations)
-        return sparse.ppr_loop(make_adj, self.H0.value, self.restart_probability, self.iterations)
+        return _propagation_run(architecture, self.H0.value, self.restart_probability, self.iterations, self.graph_dropout)[0]
 
 
 class APPNP(GNN):

@@ -50,6 +50,12 @@ class Layer(object):
         self.value = self.__forward__(architecture, features)
         return self.value
 
+    def __run__(self, architecture: VariableGenerator, features, stack, at):
+        """Optional: execute this layer TOGETHER with layers that follow it in ``stack`` (it sits at index ``at``) and return
+        (number of layers executed, output), having set their ``.value``; None (the default) = run layer by layer.  Not in the
+        reference: the container's loop (layered.py:52-55) is the same either way, a run only saves launches and intermediates."""
+        return None
+
     def loss(self):
         """output_regularize * tf.nn.l2_loss(value) = output_regularize * sum(value^2)/2 (layered.py:83-86)."""
         if self.output_regularize == 0:
@@ -85,9 +91,17 @@ class Layered(VariableGenerator):
     def top_shape(self):
         return self._stack[-1].output_shape if self._stack else self.input_shape
 
+    fuse_runs = True                             # let layers execute runs of their kind in one go (Layer.__run__); False: strictly layer by layer
+
     def __call__(self, features):
-        for layer in self._stack:
-            features = layer(self, features)
+        stack, at = self._stack, 0
+        while at < len(stack):                   # layered.py:52-55, except that a layer may take the ones that follow it along
+            done = stack[at].__run__(self, features, stack, at) if self.fuse_runs else None
+            if done is None:
+                features = stack[at](self, features)
+                at += 1
+            else:
+                at, features = at + done[0], done[1]
         return features
 
     # -- training mode -----------------------------------------------------------------------------------

@@ -41,6 +41,7 @@ Tests on CPU ranks (gloo) supply their own checker backend: this module never im
 from __future__ import annotations
 
 import contextlib
+import os
 import time
 
 import torch
@@ -260,7 +261,7 @@ class Comm:
             dist.barrier(group=self.group)
 
     # ---- which streams carry the exchanges ----------------------------------------------------------------------------------
-    def tune_overlap(self, device, force=False, lanes=4, groups=4):
+    def tune_overlap(self, device, force=False, lanes=4, groups=4, seconds=20.0):
         """Places the exchange so that transfers run BESIDE the compute stream's kernels.  HIP multiplexes streams onto a few
         hardware queues (four unless GPU_MAX_HW_QUEUES says otherwise), and two streams matter here: the exchange lane, which
         holds the event waits around every RCCL group call, and the stream torch gives the process group for RCCL's own kernels.
@@ -269,22 +270,58 @@ class Comm:
         for both (tools/overlap_probe3.py, profiles/NOTES.md).  Probe: a send / recv of this rank to ITSELF, issued from each of
         a few fresh lane streams, beside a few matrix products of the compute stream; when no lane hides the transfer on some
         rank the group's own stream is the one in the way, and the probe repeats on a fresh process group (up to ``groups``).
-        The lane is each rank's own choice (``self.lane_stream``); the group is agreed on (``self.group``).  Collective; a no-op
-        for one rank, for sub-groups of a process grid, and for backends other than "nccl".  Returns the probe table (kept in
-        ``self.overlap_probe``)."""
+        The lane is each rank's own choice (``self.lane_stream``); the group is agreed on (``self.group``).
+
+        Collective, and every decision in it is: a step that fails on ONE rank (an allocation, a new group, a transfer) is agreed
+        on by all (all_reduce MIN of an ok flag) before anyone moves on, so no rank is ever left in a collective the others have
+        given up -- on failure every rank keeps what was chosen so far (at worst the defaults) together.  ``seconds``: wall-clock
+        cap (the slowest rank's clock), checked between groups.  Groups created and not chosen are destroyed.  A no-op for one
+        rank, for sub-groups of a process grid, for backends other than "nccl", and when GNX_TUNE_OVERLAP=0.  Returns the probe
+        table (kept in ``self.overlap_probe``; ``self.overlap_status`` says what happened, also when the probe bailed out)."""
         if getattr(self, "overlap_probe", None) is not None:
             return self.overlap_probe
         self.overlap_probe, self.lane_stream = [], None
+        status = self.overlap_status = {"ran": False, "reason": None, "seconds": 0.0, "groups_tried": 0, "groups_destroyed": 0}
+        if os.environ.get("GNX_TUNE_OVERLAP", "1") == "0":
+            status["reason"] = "disabled (GNX_TUNE_OVERLAP=0)"
+            return self.overlap_probe
         if device.type != "cuda" or self.solo or self.group is not None or not dist.is_initialized() or dist.get_backend() != "nccl":
+            status["reason"] = "not applicable (needs the default process group on the nccl backend)"
             return self.overlap_probe
         if self.size == 1 and not force:
+            status["reason"] = "one rank"
             return self.overlap_probe
         me = dist.get_rank()
-        A = torch.randn(4096, 4096, device=device)
-        B = torch.randn(4096, 4096, device=device)
-        C = torch.empty_like(A)
-        src = torch.empty(256 << 20, dtype=torch.float32, device=device).normal_()         # 1 GiB message: about a millisecond of RCCL kernel
-        dst = torch.empty_like(src)
+        t_start = time.perf_counter()
+
+        def agree(ok):
+            """True when EVERY rank says ok (collective on the default group)."""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def slowest(x):
+            t = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        # probe buffers first, sized from what is free (the block's entries are on the device already): at most 1 GiB per message,
+        # at most 1/16 of the free memory for each of the two
+        problem = ""
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+            floats = int(min(256 << 20, max(free // 64, 1 << 20)))
+            A = torch.randn(4096, 4096, device=device)
+            B = torch.randn(4096, 4096, device=device)
+            C = torch.empty_like(A)
+            src = torch.empty(floats, dtype=torch.float32, device=device).normal_()    # about a millisecond of RCCL kernel at 1 GiB
+            dst = torch.empty_like(src)
+        except Exception as exc:
+            problem = repr(exc)[:200]
+        if not agree(not problem):
+            status["reason"] = "probe buffers could not be allocated on some rank" + (": " + problem if problem else "")
+            return self.overlap_probe
+        status["message_bytes"] = floats * 4
         HIDES = 0.75                                                       # measured: 0.5-0.6 beside the products when placed well, 0.85-1.1 when not
 
         def products():
@@ -311,31 +348,60 @@ class Comm:
         streams = [torch.cuda.Stream(device) for _ in range(max(1, lanes))]
         self._probe_lanes = streams                                        # kept alive: a freed stream's queue slot would be handed out again
         chosen = None                                                      # (worst rank's share, group, this rank's lane, labels)
+        made = []                                                          # groups this probe created
         for g in range(max(1, groups)):
-            group = None if g == 0 else dist.new_group(list(range(dist.get_world_size())), backend="nccl")
-            transfer(streams[0], group)                                    # (first call of a group: communicator and stream set-up, untimed)
-            t_c = ms(products)
+            group, problem = None, ""
+            if g > 0:
+                try:
+                    group = dist.new_group(list(range(dist.get_world_size())), backend="nccl")
+                    made.append(group)
+                except Exception as exc:
+                    problem = repr(exc)[:200]
+            if not agree(not problem):
+                status["reason"] = f"group {g} could not be created on some rank" + (": " + problem if problem else "")
+                break
+            status["groups_tried"] = g + 1
             mine = None
-            for k, lane in enumerate(streams):
-                t_x = ms(lambda: transfer(lane, group))
-                t_both = ms(lambda: (transfer(lane, group), products()))
-                exposed = max(t_both - t_c, 0.0) / max(t_x, 1e-6)          # share of the transfer that did NOT hide
-                self.overlap_probe.append(dict(group=g, lane=k, products_ms=t_c, transfer_ms=t_x, together_ms=t_both, exposed_share=exposed))
-                if mine is None or exposed < mine[0] - 0.1:                # (ties: the first)
-                    mine = (exposed, lane, k)
-                if exposed < HIDES:
-                    break
-            flag = torch.tensor([mine[0]], dtype=torch.float64, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)                    # the step takes the slowest rank's time
-            worst = float(flag.item())
+            try:
+                transfer(streams[0], group)                                # (first call of a group: communicator and stream set-up, untimed)
+                t_c = ms(products)
+                for k, lane in enumerate(streams):
+                    t_x = ms(lambda: transfer(lane, group))
+                    t_both = ms(lambda: (transfer(lane, group), products()))
+                    exposed = max(t_both - t_c, 0.0) / max(t_x, 1e-6)      # share of the transfer that did NOT hide
+                    self.overlap_probe.append(dict(group=g, lane=k, products_ms=t_c, transfer_ms=t_x, together_ms=t_both, exposed_share=exposed))
+                    if mine is None or exposed < mine[0] - 0.1:            # (ties: the first)
+                        mine = (exposed, lane, k)
+                    if exposed < HIDES:
+                        break
+            except Exception as exc:                                       # (a transfer to oneself involves no other rank: the others finish theirs)
+                problem = repr(exc)[:200]
+            if not agree(not problem and mine is not None):
+                status["reason"] = f"the probe of group {g} failed on some rank" + (": " + problem if problem else "")
+                break
+            worst = slowest(mine[0])                                       # the step takes the slowest rank's time
             if chosen is None or worst < chosen[0] - 0.1:
                 chosen = (worst, group, mine[1], (g, mine[2]))
             if worst < HIDES:
                 break
-        self.group, self.lane_stream = chosen[1], chosen[2]
-        for rec in self.overlap_probe:
-            rec["chosen"] = (rec["group"], rec["lane"]) == chosen[3]
-        self.overlap_exposed_worst_rank = chosen[0]
+            if slowest(time.perf_counter() - t_start) > seconds:
+                status["reason"] = f"time cap of {seconds:.0f} s reached after group {g}"
+                break
+        if chosen is not None:
+            self.group, self.lane_stream = chosen[1], chosen[2]
+            for rec in self.overlap_probe:
+                rec["chosen"] = (rec["group"], rec["lane"]) == chosen[3]
+            self.overlap_exposed_worst_rank = chosen[0]
+            status.update(ran=True, chosen_group=chosen[3][0], chosen_lane=chosen[3][1], exposed_share_worst_rank=chosen[0])
+        for group in made:                                                 # (same list, same order on every rank)
+            if chosen is None or group is not chosen[1]:
+                try:
+                    dist.destroy_process_group(group)
+                    status["groups_destroyed"] += 1
+                except Exception:
+                    pass
+        del A, B, C, src, dst
+        status["seconds"] = round(time.perf_counter() - t_start, 2)
         return self.overlap_probe
 
     def alltoallv(self, chunks):
@@ -504,7 +570,8 @@ class ShardedGraph:
     MIN_INTERIOR_SHARE = 0.05      # share of a block's entries that must sit in interior rows for the interior / boundary split to pay
 
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
-                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False, early_pull=False):
+                 relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False, early_pull=False,
+                 tune_overlap=True):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
         (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.  Collective: every rank of the
         vertex partition (``comm`` / ``group``) must call it with the same options.
@@ -516,6 +583,8 @@ class ShardedGraph:
         descending entry count -- a legal preprocessing step that makes the sub-wave kernels
         5-20 % faster; propagate() permutes H0 on the way in and the result on the way out.
         ``early_pull``: propagate() sends the pulled rows ahead of the pushed partial sums (see propagate).
+        ``tune_overlap``: probe once per communicator where the exchange runs beside the compute stream (Comm.tune_overlap;
+        collective, capped in time, GNX_TUNE_OVERLAP=0 disables it as well).
         ``edge_dropout``: build the block for TRAINING with per-iteration edge dropout (layered.py:47-50 + gnn.py:41-42):
         raw values (``normalized`` is ignored -- every iteration re-normalises its own dropped entries), classic halo, whole
         rows; use dropped_scales / propagate_dropped / propagate_dropped_backward instead of propagate()."""
@@ -577,12 +646,11 @@ class ShardedGraph:
         if self.world == 1:
             self._build_single_block(rowptr, colidx, nvals, relabel)
         else:
-            if hasattr(self.comm, "tune_overlap"):
-                try:                                         # (once per Comm) an exchange-lane stream whose transfers run beside the compute stream
-                    self.comm.tune_overlap(dev)
-                except Exception as exc:                     # placement is an optimisation: a probe that cannot run (memory, a transport
-                    self.comm.overlap_probe = [{"error": repr(exc)}]        # without self-sends) leaves the defaults in place
-                    self.comm.lane_stream = None
+            if tune_overlap and hasattr(self.comm, "tune_overlap"):
+                # (once per Comm) an exchange-lane stream whose transfers run beside the compute stream.  Every failure inside is agreed
+                # on by all ranks before anyone continues (see Comm.tune_overlap), so nothing is caught here: an exception that does
+                # escape is a bug worth seeing, not a state to continue from with ranks that may have diverged
+                self.comm.tune_overlap(dev)
                 self.group = self.comm.group
                 if getattr(self.comm, "lane_stream", None) is not None:
                     self._lanes = _Lanes(dev, self.comm.lane_stream)

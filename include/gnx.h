@@ -216,8 +216,9 @@ int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const 
  * d_out, d_work and d_H0 must be distinct buffers.  Two things the loop does that K separate gnx_ppr_step calls do not:
  *   - rows without stored entries (a * H0 after every iteration) are computed when each buffer is first a destination and left
  *     alone afterwards (GNX_ACT_SKIP_EMPTY) -- same bits, fewer bytes;
- *   - for C <= 16 on graphs of at least 2^20 vertices (no diagonal) the iterations run on a degree-relabelled copy of the
- *     matrix that the handle builds on first use (+ about 12 bytes per entry and an [n, C] scratch, owned by the handle): H0 is
+ *   - for C <= 32 on graphs of at least 2^20 vertices (no diagonal) the iterations run on a degree-relabelled copy of the
+ *     matrix (heaviest vertices first; inside a degree bin the vertices follow their most popular neighbour's rank) that the
+ *     handle builds on first use (+ about 12 bytes per entry and an [n, C] scratch, owned by the handle): H0 is
  *     permuted on the way in, the last iteration scatters back into the caller's row order; a row's columns are then summed in
  *     the relabelled order, so the result equals the step-by-step one up to float32 rounding. */
 int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0,

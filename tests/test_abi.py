@@ -64,3 +64,56 @@ def test_no_fallback_on_cpu():
     src = "".join(open(os.path.join(ROOT, "gnn-tf_amd", "gnntf", f)).read()
                   for f in os.listdir(os.path.join(ROOT, "gnn-tf_amd", "gnntf")) if f.endswith(".py"))
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_halo_plan_layout_is_host_arithmetic():
+    """gnx_halo_plan_create / _layout compute the layout of a block's feature buffer and send buffer on the HOST (the device
+    pointers they borrow are not dereferenced): [regions of lower ranks | local rows | regions of higher ranks], region(q) =
+    [rows pulled from q | partial sums pushed by q]; send buffer = [pulled rows, peer by peer | pushed sums, peer by peer].
+    Also the error paths.  (Runs under AddressSanitizer + UBSan in tools/hostcheck.sh.)"""
+    from gnntf import _native
+    lib = _native.lib()
+    P, me, n_local = 4, 1, 100
+    arr = lambda xs: (ctypes.c_int64 * P)(*xs)
+    recv_pull, recv_push = [5, 0, 7, 2], [0, 0, 0, 0]
+    send_pull, send_push = [3, 0, 4, 1], [0, 0, 0, 0]
+    fake_device_list = ctypes.c_void_p(4096)                     # borrowed, never read by the plan's host code
+    plan = ctypes.c_void_p()
+    assert lib.gnx_halo_plan_create(P, me, n_local, arr(recv_pull), arr(recv_push), arr(send_pull), arr(send_push), fake_device_list, None,
+                                    ctypes.byref(plan)) == 0, lib.gnx_last_error()
+    n_buf, local0, n_send, n_send_pull = (ctypes.c_int64() for _ in range(4))
+    recv0, pull0, push0 = arr([0] * P), arr([0] * P), arr([0] * P)
+    assert lib.gnx_halo_plan_layout(plan, ctypes.byref(n_buf), ctypes.byref(local0), ctypes.byref(n_send), ctypes.byref(n_send_pull),
+                                    recv0, pull0, push0) == 0
+    assert (n_buf.value, local0.value, n_send.value, n_send_pull.value) == (114, 5, 8, 8)
+    assert list(recv0) == [0, 105, 105, 112] and list(pull0) == [0, 3, 3, 7] and list(push0) == [8, 8, 8, 8]
+    assert lib.gnx_halo_plan_layout(plan, None, None, None, None, None, None, None) == 0       # every output is optional
+    assert lib.gnx_halo_pack(plan, 99, None, 0, 0, None, 0, None) == -1 and b"invalid part" in lib.gnx_last_error()
+    assert lib.gnx_halo_pack(plan, _native.HALO_ALL, None, 4, 4, None, 4, None) == -1 and b"NULL buffer" in lib.gnx_last_error()
+    assert lib.gnx_halo_exchange(plan, _native.HALO_ALL, None, None, None, 4, None) == -1
+    assert lib.gnx_halo_plan_destroy(plan) == 0
+    # refused: negative counts; pulled rows without their source list; pushed sums without a push graph; self out of range
+    bad = ctypes.c_void_p()
+    assert lib.gnx_halo_plan_create(P, me, n_local, arr([1, 0, -1, 0]), arr(recv_push), arr(send_pull), arr(send_push), fake_device_list, None,
+                                    ctypes.byref(bad)) == -1 and not bad.value
+    assert lib.gnx_halo_plan_create(P, me, n_local, arr(recv_pull), arr(recv_push), arr(send_pull), arr(send_push), None, None,
+                                    ctypes.byref(bad)) == -1 and b"source list" in lib.gnx_last_error()
+    assert lib.gnx_halo_plan_create(P, me, n_local, arr(recv_pull), arr([0, 0, 3, 0]), arr(send_pull), arr([0, 0, 2, 0]), fake_device_list, None,
+                                    ctypes.byref(bad)) == -1
+    assert lib.gnx_halo_plan_create(P, P, n_local, arr(recv_pull), arr(recv_push), arr(send_pull), arr(send_push), fake_device_list, None,
+                                    ctypes.byref(bad)) == -1 and b"bad rank" in lib.gnx_last_error()
+    assert lib.gnx_halo_plan_layout(None, None, None, None, None, None, None, None) == -1
+    assert lib.gnx_halo_plan_destroy(None) == 0
+
+
+def test_null_and_range_checks_of_the_compute_entries():
+    """Every compute entry checks its handle / pointers / sizes before it touches the device: callable without a GPU."""
+    from gnntf import _native
+    lib = _native.lib()
+    assert lib.gnx_appnp_propagate(None, None, None, None, 0.1, 10, 8, None, None, None) == -1
+    assert b"NULL handle" in lib.gnx_last_error()
+    assert lib.gnx_spmm(None, None, None, None, 8, 8, None, 0, 1.0, 0.0, 0, None, 8, None) == -1
+    assert lib.gnx_graph_destroy(None) == 0
+    assert lib.gnx_stream_copy(None, None, 6, None) == -1 and b"multiple of 4" in lib.gnx_last_error()
+    assert lib.gnx_stream_copy(None, None, 0, None) == 0
+    assert lib.gnx_linear_combination(0, None, None, 16, None, None) == -1

@@ -223,9 +223,9 @@ def test_k_loop_skips_settled_empty_rows_bitwise(gnntf):
 
 
 def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
-    """gnx_appnp_propagate at C <= 16 on a large graph runs on the degree-relabelled copy of the matrix (H0 permuted in, the last
+    """gnx_appnp_propagate at C <= 32 on a large graph runs on the degree-relabelled copy of the matrix (H0 permuted in, the last
     iteration scattered back): same result as K plain steps up to float32 rounding (the columns of a row are summed in another
-    order), for every K parity, unaligned widths, weighted directed patterns and empty rows; C > 16 keeps the plain path bitwise."""
+    order), for every K parity, unaligned widths, weighted directed patterns and empty rows; C > 32 keeps the plain path bitwise."""
     n = 1_200_000
     gen = torch.Generator(device="cuda").manual_seed(5)
     rows = (torch.rand(6_000_000, device="cuda", generator=gen) ** 3 * (n * 0.7)).long()          # skewed; rows above 0.7 n stay empty
@@ -234,14 +234,14 @@ def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
     vals = torch.rand(idx.shape[0], device="cuda", generator=gen) + 0.5
     g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, vals, (n, n)), device="cuda:0")
     adj = gnntf.normalize(g, "symmetric")
-    for C in (7, 8, 16, 24):
+    for C in (7, 8, 16, 24, 32, 40):
         H0 = torch.rand(n, C, device="cuda", generator=gen) * 2 - 1
         for K in (1, 2, 3, 10):
             H = H0
             for _ in range(K):
                 H = gnntf.ppr_step(adj, H, H0, 0.15)
             got = gnntf.appnp_propagate(adj, H0, a=0.15, iterations=K)
-            if C > 16:
+            if C > 32:
                 assert torch.equal(got, H)
             else:
                 assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
@@ -718,6 +718,92 @@ def test_fused_ppr_loop_equals_layers(gnntf):
     default.training_mode(False); ref.training_mode(False)
     with torch.no_grad():
         assert torch.equal(default(default.features), ref(ref.features))
+
+
+def test_hand_built_ppr_iteration_stack_runs_fused(gnntf):
+    """The usage contract of reference demos/custom_layers.py:8-13 -- ``H0 = gnn.add(Dense(...)); for _ in range(10):
+    gnn.add(PPRIteration(H0, 0.1))`` -- executes as ONE fused loop (Layer.__run__) and is bit for bit what the ten layers give
+    one by one: eval mode, training mode (same sequence of edge-dropout masks), gradients, and the intermediate layers' lazily
+    computed ``.value``."""
+    coo, vals, shape = graphs.cora_shaped(seed=3)[:3]
+    X = np.random.default_rng(0).standard_normal((shape[0], 24)).astype(np.float32)
+
+    def build():
+        gnntf.set_seed(7)
+        gnn = gnntf.GNN(gnntf.SparseCOO(coo, vals, shape), X)
+        gnn.add(gnntf.Dense(32, activation=gnntf.relu, dropout=0.0))
+        H0 = gnn.add(gnntf.Dense(7, activation=gnntf.relu, regularize=False))
+        for _ in range(10):
+            gnn.add(gnntf.PPRIteration(H0, 0.1))
+        return gnn
+
+    fused, plain = build(), build()
+    plain.fuse_runs = False
+    for v, w in zip(fused.vars(), plain.vars()):
+        w.assign(v.identity())
+    launches = []
+    real = gnntf.sparse.ppr_step
+    # eval mode: one library call instead of ten
+    fused.training_mode(False); plain.training_mode(False)
+    with torch.no_grad():
+        gnntf.sparse.ppr_step = lambda *a, **k: (launches.append(1), real(*a, **k))[1]
+        try:
+            out_f = fused(fused.features)
+            assert not launches                                   # no single steps were launched ...
+            out_p = plain(plain.features)
+            assert len(launches) == 10                            # ... the layer-by-layer container launches ten
+        finally:
+            gnntf.sparse.ppr_step = real
+        assert torch.equal(out_f, out_p)
+        its_f = [l for l in fused.layers() if isinstance(l, gnntf.PPRIteration)]
+        its_p = [l for l in plain.layers() if isinstance(l, gnntf.PPRIteration)]
+        assert torch.equal(its_f[-1].value, out_f)
+        for k in (0, 4, 8):                                       # an intermediate iteration's value: computed when read
+            assert its_f[k].__dict__.get("_value") is None
+            assert torch.equal(its_f[k].value, its_p[k].value)
+    # training mode: the same masks, outputs and gradients
+    outs, grads = [], []
+    for model in (fused, plain):
+        gnntf.set_seed(11)
+        model._mask_calls = 0
+        for v in model.vars():
+            v.var.grad = None
+        with model:
+            out = model(model.features)
+            (out * out).sum().backward()
+        outs.append(out.detach())
+        grads.append([v.var.grad.clone() for v in model.vars() if v.trainable])
+    assert torch.equal(outs[0], outs[1])
+    for gf, gp in zip(grads[0], grads[1]):
+        np.testing.assert_allclose(gf.cpu().numpy(), gp.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # what is NOT a plain run stays layer by layer: another activation, feature dropout, a run that does not start at H0
+    gnn = build()
+    gnn.add(gnntf.PPRIteration(gnn.layers()[1], 0.1, activation=gnntf.relu))
+    gnn.add(gnntf.PPRIteration(gnn.layers()[1], 0.2))
+    gnn.training_mode(False)
+    with torch.no_grad():
+        got = gnn(gnn.features)
+        H0v = gnn.layers()[1].value
+        adj = gnn.get_adjacency(0.5)
+        want = gnntf.ppr_step(adj, torch.relu(gnntf.ppr_step(adj, gnntf.appnp_propagate(adj, H0v, 0.1, 10), H0v, 0.1)), H0v, 0.2)
+    assert torch.equal(got, want)
+
+
+def test_appnp_layer_list_matches_the_reference_when_not_fused(gnntf):
+    """filter.py:30-35: Dropout, one Dense per latent width, the output Dense, then ``iterations`` PPRIteration layers.
+    ``fused=False`` reproduces exactly that list (the default collapses the iterations into one PPRLoop layer -- a structural
+    difference stated in README / INTEGRATION; results are the same)."""
+    import networkx as nx
+    G = nx.path_graph(6)
+    X = np.eye(6, dtype=np.float32)
+    model = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, latent_dims=[8, 4], iterations=10, fused=False)
+    names = [type(l).__name__ for l in model.layers()]
+    assert names == ["Dropout", "Dense", "Dense", "Dense"] + ["PPRIteration"] * 10
+    its = model.layers()[4:]
+    assert all(l.H0 is model.layers()[3] and l.restart_probability == 0.1 and l.graph_dropout == 0.5 for l in its)
+    default = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, latent_dims=[8, 4], iterations=10)
+    assert [type(l).__name__ for l in default.layers()] == ["Dropout", "Dense", "Dense", "Dense", "PPRLoop"]
+    assert default.layers()[-1].iterations == 10 and default.layers()[-1].H0 is default.layers()[3]
 
 
 def test_train_and_predict_end_to_end(gnntf):

@@ -172,3 +172,32 @@ def test_npz_dataset_roundtrip(tmp_path):
     want = gnntf.graph2adj(G)
     assert adj.indices.tolist() == want.indices.tolist() and adj.dense_shape == (5, 5)
     assert l2.tolist() == labels.tolist() and (f2 == X).all() and (train, valid, test) == ([0, 1], [2], [3, 4])
+
+
+def test_container_lets_a_layer_take_the_following_ones_along():
+    """Layer.__run__ (not in the reference): the container's loop (layered.py:52-55) offers every layer the chance to execute
+    a run of layers in one go; the default declines, ``fuse_runs = False`` never asks, and either way the output and every
+    layer's ``.value`` are what the plain loop gives."""
+    class Twice(gnntf.Layer):
+        def __build__(self, arch):
+            return arch.top_shape()
+
+        def __forward__(self, arch, x):
+            return 2 * x
+
+        def __run__(self, arch, x, stack, at):
+            run = [l for l in stack[at:at + 3] if isinstance(l, Twice)]
+            if len(run) < 2:
+                return None
+            calls.append(len(run))
+            for k, layer in enumerate(run):
+                layer.value = x * 2 ** (k + 1)
+            return len(run), run[-1].value
+
+    calls = []
+    arch = gnntf.Layered((2, 2), [Twice(), Twice(), Twice(), Twice()])
+    x = torch.ones(2, 2)
+    assert torch.equal(arch(x), 16 * x) and calls == [3]              # three in one go, the fourth alone
+    assert [float(l.value[0, 0]) for l in arch.layers()] == [2, 4, 8, 16]
+    arch.fuse_runs = False
+    assert torch.equal(arch(x), 16 * x) and calls == [3]
