@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "gnx_internal.h"
+#include <mutex>
 
 using namespace gnx;
 
@@ -283,10 +284,11 @@ bool ring_eligible(const DenseArgs &p, bool x_aligned, int nt) {
 template <int NT, int WAVES, int RING>
 int launch_ring_as(const DenseArgs &p, hipStream_t s) {
     const size_t lds_bytes = ((size_t)p.F * NT * 16 + (size_t)WAVES * RING * 16 * RING_BK) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    const int attr_dev = PerDeviceOnce::device();
+    if (configured.need(attr_dev)) {
         GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_ring<NT, WAVES, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-        configured = true;
+        configured.set(attr_dev);
     }
     const int64_t n_tiles = (p.n + 15) / 16;
     int cus = 256;
@@ -471,23 +473,30 @@ bool wreg_eligible(const DenseArgs &p, bool x_aligned) {
            p.n >= 16 * 1024 && p.n < (1ll << 31) && p.ldx < (1ll << 30) && p.ldo < (1ll << 30);
 }
 
-// sixteen bytes of zeros on the device (per process: one process per GPU)
+// a block of zeros on the CURRENT device (one per device the process drives; never freed)
 const float *device_zeros() {
-    static float *z = nullptr;
-    if (!z) {
-        if (hipMalloc((void **)&z, 256) != hipSuccess) { z = nullptr; return nullptr; }
-        if (hipMemset(z, 0, 256) != hipSuccess) { (void)hipFree(z); z = nullptr; return nullptr; }
+    static std::mutex lock;
+    static float *z[64] = {};
+    const int dev = PerDeviceOnce::device();
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> hold(lock);
+    if (!z[dev]) {
+        float *q = nullptr;
+        if (hipMalloc((void **)&q, 256) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, 256) != hipSuccess) { (void)hipFree(q); return nullptr; }
+        z[dev] = q;
     }
-    return z;
+    return z[dev];
 }
 
 template <int NT, int KS, int RING, bool RELU, bool PAD>
 int launch_wreg_as(const DenseArgs &p, hipStream_t s) {
     const size_t lds_bytes = (size_t)4 * RING * 16 * RING_BK * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    const int attr_dev = PerDeviceOnce::device();
+    if (configured.need(attr_dev)) {
         GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_wreg<NT, KS, RING, RELU, PAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-        configured = true;
+        configured.set(attr_dev);
     }
     const int64_t n_tiles = (p.n + 15) / 16;
     int cus = 256;
@@ -734,10 +743,11 @@ int launch_wgrad_acc(const float *X, int64_t ldx, int64_t F, const float *G, int
                      int64_t *n_slabs, hipStream_t s) {
     using Cfg = WgradAcc<MT, NT>;
     const size_t lds_bytes = (size_t)4 * Cfg::RING * Cfg::STAGE * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce configured;
+    const int attr_dev = PerDeviceOnce::device();
+    if (configured.need(attr_dev)) {
         GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wgrad_acc<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-        configured = true;
+        configured.set(attr_dev);
     }
     int cus = 256;
     int dev = 0;

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "gnx_internal.h"
+#include <algorithm>
 
 #include <rocprim/rocprim.hpp>
 
@@ -301,8 +302,29 @@ int build_long_plan(Csr &m, hipStream_t s) {
     return GNX_OK;
 }
 
-int ensure_partial(gnx_graph *g, size_t bytes) {
+// A stream that is being captured into a hipGraph must not see hipMalloc / hipFree / synchronisation: the lazily built parts of
+// a handle (long-row slab, transposed structure, relabelled copy) refuse to grow there and say how to prepare them.
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+
+#define GNX_NOT_WHILE_CAPTURING(s, what)                                                                                         \
+    do {                                                                                                                         \
+        if (stream_is_capturing(s)) {                                                                                            \
+            set_error("%s would have to be allocated while the stream is being captured into a hipGraph: call "                  \
+                      "gnx_graph_reserve(handle, C, flags) -- or run the same call once eagerly -- before the capture begins", what); \
+            return GNX_ERR_UNSUPPORTED;                                                                                          \
+        }                                                                                                                        \
+    } while (0)
+
+// The slab the long-row chunks of a launch write their partial sums to ([chunks x C] floats).  It only ever grows; growing frees
+// and allocates (an implicit device synchronisation), which is why it never happens under capture (gnx_graph_reserve sizes it
+// ahead of time for the widest C a client will use).
+int ensure_partial(gnx_graph *g, size_t bytes, hipStream_t s) {
     if (bytes <= g->partial_bytes) return GNX_OK;
+    GNX_NOT_WHILE_CAPTURING(s, "the long-row slab of this handle");
     if (g->partial) (void)hipFree(g->partial);
     g->partial = nullptr; g->partial_bytes = 0;
     GNX_HIP(hipMalloc((void **)&g->partial, bytes));
@@ -322,6 +344,7 @@ static void drop_transpose(gnx_graph *g) {
 
 int ensure_transpose(gnx_graph *g, hipStream_t s) {
     if (g->has_t) return GNX_OK;
+    GNX_NOT_WHILE_CAPTURING(s, "the transposed structure of this handle");
     struct Undo { gnx_graph *g; ~Undo() { if (g && !g->has_t) drop_transpose(g); } } undo{g};   // no half-built state on failure
     const Csr &a = g->a;
     Csr &t = g->t;
@@ -373,8 +396,9 @@ static void drop_relabel(gnx_graph *g) {
     g->has_r = false;
 }
 
-int ensure_relabel_features(gnx_graph *g, size_t bytes) {
+int ensure_relabel_features(gnx_graph *g, size_t bytes, hipStream_t s) {
     if (bytes <= g->r_feat_bytes) return GNX_OK;
+    GNX_NOT_WHILE_CAPTURING(s, "the feature scratch of this handle's relabelled copy");
     if (g->r_feat) (void)hipFree(g->r_feat);
     g->r_feat = nullptr; g->r_feat_bytes = 0;
     GNX_HIP(hipMalloc((void **)&g->r_feat, bytes));
@@ -388,6 +412,7 @@ int ensure_relabel_features(gnx_graph *g, size_t bytes) {
 // a large square graph.
 int ensure_relabel(gnx_graph *g, hipStream_t s) {
     if (g->has_r) return GNX_OK;
+    GNX_NOT_WHILE_CAPTURING(s, "the relabelled copy of this handle");
     struct Undo { gnx_graph *g; ~Undo() { if (g && !g->has_r) drop_relabel(g); } } undo{g};
     const Csr &a = g->a;
     Csr &r = g->r;
@@ -476,6 +501,28 @@ int gnx_graph_destroy(gnx_graph_t g) {
     if (g->r_order) (void)hipFree(g->r_order);
     if (g->r_feat) (void)hipFree(g->r_feat);
     delete g;
+    return GNX_OK;
+}
+
+int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_reserve: NULL handle");
+    GNX_CHECK_ARG(C >= 1 && (flags & ~(GNX_RESERVE_TRANSPOSED | GNX_RESERVE_K_LOOP)) == 0, "gnx_graph_reserve: bad width / flags");
+    hipStream_t s = (hipStream_t)stream;
+    GNX_CHECK_ARG(!stream_is_capturing(s), "gnx_graph_reserve: the stream is being captured -- reserve before the capture begins");
+    int64_t chunks = g->a.n_chunks;
+    if (flags & GNX_RESERVE_TRANSPOSED) {
+        int rc = ensure_transpose(g, s);
+        if (rc != GNX_OK) return rc;
+        chunks = std::max(chunks, g->t.n_chunks);
+    }
+    if ((flags & GNX_RESERVE_K_LOOP) && C <= RELABEL_MAX_C && g->a.n_rows == g->a.n_cols && g->a.n_rows >= (1 << 20) && g->a.nnz >= g->a.n_rows) {
+        int rc = ensure_relabel(g, s);
+        if (rc != GNX_OK) return rc;
+        rc = ensure_relabel_features(g, (size_t)g->a.n_rows * (size_t)C * sizeof(float), s);
+        if (rc != GNX_OK) return rc;
+        chunks = std::max(chunks, g->r.n_chunks);
+    }
+    if (chunks > 0) return ensure_partial(g, (size_t)chunks * (size_t)C * sizeof(float), s);
     return GNX_OK;
 }
 

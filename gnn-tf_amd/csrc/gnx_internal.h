@@ -2,13 +2,14 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
 
 #include "../../include/gnx.h"
 
-#define GNX_VERSION_NUM 300 /* 0.3.0 */
+#define GNX_VERSION_NUM GNX_ABI_VERSION /* 0.4.0: the header's number */
 
 namespace gnx {
 
@@ -115,9 +116,10 @@ namespace gnx {
 int build_long_plan(Csr &m, hipStream_t s);
 void free_csr(Csr &m);
 int ensure_transpose(gnx_graph *g, hipStream_t s);
-int ensure_partial(gnx_graph *g, size_t bytes);
+int ensure_partial(gnx_graph *g, size_t bytes, hipStream_t s);
+bool stream_is_capturing(hipStream_t s);
 int ensure_relabel(gnx_graph *g, hipStream_t s);
-int ensure_relabel_features(gnx_graph *g, size_t bytes);
+int ensure_relabel_features(gnx_graph *g, size_t bytes, hipStream_t s);
 
 // ---- counter RNG of the edge dropout: the same integer arithmetic as oracle/gnntf_oracle.py:hash_u24 ----------
 __device__ __forceinline__ uint64_t rng_fin(uint64_t z) {
@@ -188,6 +190,15 @@ struct SpmmArgs {
     int tune;
     bool skip_empty;           // GNX_ACT_SKIP_EMPTY: rows without entries are left untouched
     DropFuse fuse;
+};
+
+// "Done once" per DEVICE, not per process: a process may drive several GPUs (gnntf's nat.on_device, vertex blocks as threads), and a
+// kernel attribute set on one device says nothing about the next.  Concurrent first calls may both do the (idempotent) work.
+struct PerDeviceOnce {
+    std::atomic<uint64_t> done{0};
+    static int device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = -1; } return d; }
+    bool need(int dev) const { return dev < 0 || dev >= 64 || !((done.load(std::memory_order_acquire) >> dev) & 1u); }
+    void set(int dev) { if (dev >= 0 && dev < 64) done.fetch_or(uint64_t(1) << dev, std::memory_order_release); }
 };
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);

@@ -1278,7 +1278,7 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.act &= ~GNX_ACT_SKIP_EMPTY;
     if (m.n_rows == 0) return GNX_OK;
     if (m.n_long > 0) {
-        int rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)p.C * sizeof(float));
+        int rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)p.C * sizeof(float), s);
         if (rc != GNX_OK) return rc;
         p.partial = g->partial;
     }
@@ -1486,13 +1486,14 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
         p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.row_order = m.row_order;
         p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
         p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
-        static bool configured = false;
-        if (!configured) {
+        static PerDeviceOnce configured;
+        const int attr_dev = PerDeviceOnce::device();
+        if (configured.need(attr_dev)) {
             GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
             GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
             GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
             GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-            configured = true;
+            configured.set(attr_dev);
         }
         int cus = 256, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1508,7 +1509,7 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
         else                    hipLaunchKernelGGL((k_gcnii_dma<false, false>), grid, dim3(256), lds_bytes, s, p, d_M, ldm, d_mixed, (uint32_t)tiles_per_wave, (int64_t)m.nnz);
         g->last_kernel = "gcnii_dma_mfma";
         if (m.n_long > 0) {   // hub rows, as below
-            rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float));
+            rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float), s);
             if (rc != GNX_OK) return rc;
             p.partial = g->partial;
             p.act = GNX_ACT_NONE;
@@ -1542,7 +1543,7 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
     else              hipLaunchKernelGGL((k_spmm_gcnii<1, 4, 8>), dim3(grid), dim3(512), 0, s, p, d_M, ldm, d_mixed);
     g->last_kernel = "spmm_gcnii_mfma";
     if (m.n_long > 0) {   // hub rows: chunked partial sums -> mixed rows (into d_mixed when kept, else in place) -> transform of those rows alone
-        rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float));
+        rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float), s);
         if (rc != GNX_OK) return rc;
         p.partial = g->partial;
         p.act = GNX_ACT_NONE;
@@ -1583,7 +1584,7 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
     if (C <= RELABEL_MAX_C && n >= (1 << 20) && g->a.nnz >= n && d_diag == nullptr) {
         int rc = ensure_relabel(g, s);
         if (rc != GNX_OK) return rc;
-        rc = ensure_relabel_features(g, (size_t)n * C * sizeof(float));
+        rc = ensure_relabel_features(g, (size_t)n * C * sizeof(float), s);
         if (rc != GNX_OK) return rc;
         hipLaunchKernelGGL(k_gather_vals, dim3(blocks_for(g->a.nnz, 256)), dim3(256), 0, s, d_vals ? d_vals : g->raw_vals, g->r_perm, g->a.nnz,
                            g->r_vals);

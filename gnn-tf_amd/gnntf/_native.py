@@ -10,6 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 400          # include/gnx.h GNX_ABI_VERSION: the header this binding was written against
 # GNX_LIBRARY: another build of the same library (the tuning build of tools/, `make TUNING=1` -> lib/tune/libgnx.so)
 LIB_PATH = os.environ.get("GNX_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
 
@@ -17,6 +18,7 @@ NORM = {"none": 0, "symmetric": 1, "bipartite": 2}
 EYE = {"none": 0, "before": 1, "after": 2}
 ACT_NONE, ACT_RELU, ACT_SKIP_EMPTY = 0, 1, 256
 HALO_ALL, HALO_PULL, HALO_PUSH = 0, 1, 2
+RESERVE_TRANSPOSED, RESERVE_K_LOOP = 1, 2
 
 # name -> (restype, argtypes); must list every symbol include/gnx.h declares
 SIGNATURES = {
@@ -30,6 +32,7 @@ SIGNATURES = {
     "gnx_graph_export": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gnx_graph_normalize": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
     "gnx_graph_normalize_t": (c_int, [c_void_p, c_int, c_int, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p]),
+    "gnx_graph_reserve": (c_int, [c_void_p, c_int64, c_int, c_void_p]),
     "gnx_graph_set_dropout_counter": (c_int, [c_void_p, c_void_p]),
     "gnx_graph_set_block": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gnx_graph_colsum": (c_int, [c_void_p, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
@@ -96,6 +99,12 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
+        # the argument lists of several entries changed under the same names at 0.3 (include/gnx.h, GNX_ABI_VERSION): a library
+        # of another minor version would be called with shifted arguments -- refused, not tried
+        version = int(handle.gnx_version())
+        if version // 100 != ABI_VERSION // 100:
+            raise Exception(f"gnntf: {LIB_PATH} implements ABI {version}, this package binds ABI {ABI_VERSION}: rebuild the library "
+                            f"(make -C gnn-tf_amd/csrc)")
         _lib = handle
     return _lib
 

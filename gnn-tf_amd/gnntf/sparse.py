@@ -109,6 +109,15 @@ class DeviceGraph:
     def last_kernel(self) -> str:
         return (nat.lib().gnx_graph_last_kernel(self._h) or b"").decode()
 
+    def reserve(self, C, transposed=False, k_loop=False):
+        """Builds NOW what the launches otherwise build on first use, sized for feature rows of up to ``C`` floats (the long-row
+        slab; with ``transposed`` the transposed structure a backward needs; with ``k_loop`` the relabelled copy appnp_propagate
+        runs narrow widths on): those lazy builds allocate and synchronise, which a stream under hipGraph capture must not see
+        (a launch that would have to grow something there raises instead).  Call before capturing (gnx_graph_reserve)."""
+        flags = (nat.RESERVE_TRANSPOSED if transposed else 0) | (nat.RESERVE_K_LOOP if k_loop else 0)
+        with nat.on_device(self.device):
+            nat.check(nat.lib().gnx_graph_reserve(self._h, int(C), flags, nat.current_stream()))
+
     def set_dropout_counter(self, counter):
         """``counter``: a one-element int64 device tensor added to every dropout stream id used with this graph (read by the
         kernels when they run), or None.  Lets a captured training step draw fresh masks on every replay."""

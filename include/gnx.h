@@ -46,7 +46,12 @@ enum { GNX_ACT_SKIP_EMPTY = 256 };
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *gnx_last_error(void);
-/* ABI version: major*10000 + minor*100 + patch. */
+/* ABI version: major*10000 + minor*100 + patch.  GNX_ABI_VERSION is what THIS header describes; a client compares it with
+ * gnx_version() of the library it loaded and refuses a mismatch in major or minor: entry points changed argument lists under
+ * the same names between 0.2 and 0.3 (gnx_halo_plan_create / _layout / _pack / _exchange gained `part` and split pull / push
+ * counts; gnx_gcnii_step's d_work became d_mixed), so a 0.2 client linked against a 0.3+ library passes shifted arguments.
+ * 0.4 adds gnx_graph_reserve and changes no existing signature. */
+#define GNX_ABI_VERSION 400
 int gnx_version(void);
 
 /* ---- graph construction ------------------------------------------------------------
@@ -93,6 +98,17 @@ int gnx_graph_export(gnx_graph_t g, int64_t *d_rowptr_out, int32_t *d_colidx_out
  * Requires a square graph for symmetric/bipartite. */
 int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropout_p, uint64_t seed,
                         uint64_t stream_id, float *d_vals_out, float *d_diag_out, void *stream);
+
+/* gnx_graph_reserve: builds, NOW, what the compute entries otherwise build on first use, sized for feature rows of up to C floats:
+ * the slab the long rows' partial sums go through (every entry), with GNX_RESERVE_TRANSPOSED the transposed structure (gnx_spmm_t,
+ * gnx_spmm_dropped(transposed), the column sums of a training step), with GNX_RESERVE_K_LOOP the relabelled copy
+ * gnx_appnp_propagate runs narrow widths on.  Those lazy builds allocate and synchronise, which a stream that is being captured
+ * into a hipGraph must not see: a compute entry that would have to grow something under capture fails with
+ * GNX_ERR_UNSUPPORTED and a message naming this call.  Reserve (or run the launch once eagerly) BEFORE capturing; replays then
+ * touch no allocator.  ("an optional caller-provided workspace" -- the workspace stays owned by the handle, the
+ * caller decides when it is sized.)  Nothing in the reference corresponds: TensorFlow eager allocates per op. */
+enum { GNX_RESERVE_TRANSPOSED = 1, GNX_RESERVE_K_LOOP = 2 };
+int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream);
 
 /* gnx_graph_set_dropout_counter: from now on every dropout stream id used with this handle is `stream_id + *d_counter`
  * (d_counter: one uint64 in device memory, read by the kernels when they run; NULL switches it off).  This is what lets a

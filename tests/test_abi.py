@@ -33,7 +33,9 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_error_string():
     from gnntf import _native
     lib = _native.lib()
-    assert lib.gnx_version() >= 100
+    header = open(os.path.join(ROOT, "include", "gnx.h")).read()
+    declared = int(re.search(r"#define GNX_ABI_VERSION (\d+)", header).group(1))
+    assert lib.gnx_version() == declared == _native.ABI_VERSION          # header, library and binding describe ONE ABI
     assert isinstance(lib.gnx_last_error(), bytes)
 
 

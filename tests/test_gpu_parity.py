@@ -720,6 +720,85 @@ def test_fused_ppr_loop_equals_layers(gnntf):
         assert torch.equal(default(default.features), ref(ref.features))
 
 
+@pytest.mark.parametrize("C", [7, 64, 256])
+def test_giant_row_against_fp32_sequential_and_fp64(gnntf, C):
+    """A row of 320,000 entries with N(0, 1) weights times N(0, 1) features -- sums that cancel -- through the long-row path
+    (512-entry chunks, partials added in chunk order), pinned two ways:
+      (i)  against float64: every element within 8 float32 roundings of its OWN sum of |terms| (the yardstick of the vertex-block
+           tests; what commit f2794eb's fuzz tolerance only widened);
+      (ii) against the oracle's C port, which adds a row's terms one after the other in float32 -- the order the reference's
+           TF-CPU kernel uses (tf.sparse.sparse_dense_matmul over the COO entries, filter.py:19): on the giant row the device
+           result must be at least as close to the exact sum as that sequential float32 sum is."""
+    import ctypes
+    import scipy.sparse as sp
+    import __graft_entry__ as ge
+    rng = np.random.default_rng(100 + C)
+    n, hub = 400_000, 320_000
+    cols_hub = rng.choice(n, size=hub, replace=False)
+    other_r = rng.integers(1, n, size=300_000)
+    other_c = rng.integers(0, n, size=300_000)
+    idx = np.unique(np.concatenate([np.stack([np.zeros(hub, dtype=np.int64), cols_hub], 1), np.stack([other_r, other_c], 1)]), axis=0)
+    vals = rng.standard_normal(idx.shape[0]).astype(np.float32)
+    X = rng.standard_normal((n, C)).astype(np.float32)
+    H0 = rng.standard_normal((n, C)).astype(np.float32)
+    a = np.float32(0.1)
+    g = make_graph(gnntf, idx, vals, (n, n))
+    got = gnntf.ppr_step(gnntf.Adjacency(g, dev(vals)), dev(X), dev(H0), float(a)).cpu().numpy()
+    A64 = sp.csr_matrix((vals.astype(np.float64), (idx[:, 0], idx[:, 1])), shape=(n, n))
+    beta = np.float64(np.float32(1.0 - np.float64(a)))
+    want = beta * (A64 @ X.astype(np.float64)) + np.float64(a) * H0.astype(np.float64)
+    terms = beta * (abs(A64) @ np.abs(X).astype(np.float64)) + np.float64(a) * np.abs(H0).astype(np.float64)
+    u = 2.0 ** -24
+    err = np.abs(got.astype(np.float64) - want)
+    assert (err <= 8 * u * terms + 1e-30).all(), float((err / (u * terms + 1e-30)).max())
+    # the float32 sequential reference (oracle/propagate_ref.c: oracle_ppr_step), rows 0 .. 0 only matter here but all are computed
+    lib = ctypes.CDLL(ge.build_oracle())
+    lib.oracle_ppr_step.restype = None
+    lib.oracle_ppr_step.argtypes = [ctypes.c_int64] + [ctypes.c_void_p] * 5 + [ctypes.c_float, ctypes.c_int64, ctypes.c_void_p]
+    rowptr, colidx, cvals = orc.coo_to_csr_coalesced(idx, vals, (n, n))
+    seq = np.empty_like(X)
+    lib.oracle_ppr_step(n, rowptr.ctypes.data, colidx.ctypes.data, cvals.ctypes.data, X.ctypes.data, H0.ctypes.data, float(a), C, seq.ctypes.data)
+    err_seq = np.abs(seq.astype(np.float64) - want)
+    rms = lambda e: float(np.sqrt((e ** 2).mean()))
+    assert rms(err[0]) <= rms(err_seq[0]), (rms(err[0]), rms(err_seq[0]))          # the giant row: chunked sums beat the sequential order
+    assert (np.abs(got - seq)[0] <= err_seq[0] + 8 * u * terms[0]).all()           # and differ from it by no more than ITS error + ours
+    np.testing.assert_allclose(got[1:], seq[1:], rtol=1e-5, atol=1e-5)             # short rows: a handful of terms either way
+
+
+def test_capture_needs_the_handle_prepared_and_reserve_prepares_it(gnntf):
+    """the lazily built parts of a handle (long-row slab, transposed structure) are never allocated under
+    hipGraph capture.  A launch whose slab would have to grow there fails with a message naming gnx_graph_reserve -- and leaves
+    the capture intact; after DeviceGraph.reserve(widest C) the FIRST launch at that width is captured and replays correctly."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(40_000, 600_000, seed=4)
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, "symmetric")
+    n = shape[0]
+    X8, X64 = dev(np.random.default_rng(0).standard_normal((n, 8)).astype(np.float32)), dev(np.random.default_rng(1).standard_normal((n, 64)).astype(np.float32))
+    gnntf.spmm(adj, X8)                                     # the slab now fits 8 columns
+    if "long" not in g.last_kernel() and "chunks" not in g.last_kernel():
+        pytest.skip("this graph has no long rows: no slab to grow")
+    torch.cuda.synchronize()
+    refused = torch.cuda.CUDAGraph()
+    with pytest.raises(Exception, match="gnx_graph_reserve"):
+        with torch.cuda.graph(refused):
+            gnntf.spmm(adj, X64)
+    torch.cuda.synchronize()
+    with pytest.raises(Exception, match="gnx_graph_reserve"):           # the transposed structure does not exist yet either
+        with torch.cuda.graph(torch.cuda.CUDAGraph()):
+            gnntf.sparse._launch(adj, X8, None, 1.0, 0.0, 0, transposed=True)
+    torch.cuda.synchronize()
+    g.reserve(64, transposed=True)
+    want_f = None
+    recorded = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(recorded):
+        out_f = gnntf.spmm(adj, X64)                        # first launch at the widest width: inside the capture
+        out_b = gnntf.sparse._launch(adj, X64, None, 1.0, 0.0, 0, transposed=True)
+    X64.mul_(2.0)                                           # replays read the buffers as they are NOW
+    recorded.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_f, gnntf.spmm(adj, X64)) and torch.equal(out_b, gnntf.sparse._launch(adj, X64, None, 1.0, 0.0, 0, transposed=True))
+
+
 def test_hand_built_ppr_iteration_stack_runs_fused(gnntf):
     """The usage contract of reference demos/custom_layers.py:8-13 -- ``H0 = gnn.add(Dense(...)); for _ in range(10):
     gnn.add(PPRIteration(H0, 0.1))`` -- executes as ONE fused loop (Layer.__run__) and is bit for bit what the ten layers give

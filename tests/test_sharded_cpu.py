@@ -140,6 +140,21 @@ def test_choose_grid_and_columns():
     assert split_columns(5, 9)[-1][1] == 5 and len(split_columns(5, 9)) == 5
 
 
+def test_overlap_probe_states_why_it_did_not_run(monkeypatch):
+    """Comm.tune_overlap records a result even when it bails out: never an exception for the caller to
+    swallow, always ``overlap_status`` -- here the branches a CPU box can reach (the probing itself needs RCCL: tests/test_gpu_rccl.py)."""
+    import torch
+    from gnntf.sharded import Comm
+    solo = Comm(solo=True)
+    assert solo.tune_overlap(torch.device("cpu")) == [] and solo.overlap_status["ran"] is False
+    assert "not applicable" in solo.overlap_status["reason"] and solo.lane_stream is None
+    assert solo.tune_overlap(torch.device("cpu")) == []                       # once per communicator
+    monkeypatch.setenv("GNX_TUNE_OVERLAP", "0")
+    off = Comm(solo=True)
+    off.tune_overlap(torch.device("cuda", 0))
+    assert off.overlap_status == {"ran": False, "reason": "disabled (GNX_TUNE_OVERLAP=0)", "seconds": 0.0, "groups_tried": 0, "groups_destroyed": 0}
+
+
 def test_cover_push_mask_properties():
     """The pull/push decision: every pushed entry's (peer, row) is pushed as a whole, a star's leaves are covered by
     its hub from both sides, and a peer whose cover is not smaller keeps the plain halo."""
