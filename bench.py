@@ -76,12 +76,13 @@ def min_bytes_per_iteration(n, nnz, C):
 
 
 def alg_bytes_dropped_iteration(n, nnz, kept, C, backward=False):
-    """One TRAINING iteration (layered.py:47-50 + gnn.py:37-42 + filter.py:19-21; gnx_spmm_dropped(_chained)) in the convention of
-    alg_bytes_per_iteration: every stored entry's column index and RAW value are read (the draw needs them), only the ``kept``
-    entries gather a neighbour row.  Forward (chained, k >= 1): + per row rowptr, D[row], the next iteration's scale, H0 and out.
-    Backward (transposed structure, no mix term): + 4 bytes per kept entry for its column's scale, per row rowptr, D[row] and out."""
+    """One TRAINING iteration (layered.py:47-50 + gnn.py:37-42 + filter.py:19-21) in the convention of alg_bytes_per_iteration:
+    every stored entry's column index and RAW value are read (the draw needs them), only the ``kept`` entries gather a neighbour
+    row.  Forward (gnx_spmm_dropped_chained, k >= 1): + per row rowptr, D[row], the next iteration's scale, H0 and out.
+    Backward (gnx_spmm_dropped_back, a middle iteration, over the transposed structure): + per row rowptr, D[row], the next step's
+    scale, the running gradient sum read and written, and the pre-scaled operand of the next step written."""
     if backward:
-        return nnz * 8 + kept * (4 * C + 4) + n * (4 + 4 + 4 * C)
+        return nnz * 8 + kept * 4 * C + n * (4 + 4 + 4 + 12 * C)
     return nnz * 8 + kept * 4 * C + n * (4 + 4 + 4 + 8 * C)
 
 
@@ -424,7 +425,9 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     with torch.no_grad():
         ms_f = median_ms(lambda: sp._launch_chained(adj1, Xd, Xd, 1.0 - a, a, True, scales[2]), reps=5, warm=2)
         kernel_f = g.last_kernel()
-        ms_b = median_ms(lambda: sp._launch(adj1, gout, None, 1.0 - a, 0.0, nat.ACT_NONE, transposed=True), reps=5, warm=2)
+        S_run, Y_run = torch.zeros_like(gout), torch.empty_like(gout)
+        ms_b = median_ms(lambda: sp._launch_back(adj1, gout, True, scales[0], S_run, 1.0, a * (1.0 - a), S_run, 1.0 - a, Y_run), reps=5, warm=2)
+        del S_run, Y_run
         ms_d = median_ms(lambda: sp.dropped_degree_scales(g, 0.5, 1, 0, K), reps=3, warm=1)
     wl = workload_name(n4, e4, C)
     roof_f = roofline_record(n, nnz, C, ms_f * 1e-3, K, "train_forward_" + wl, measured_peak,
@@ -432,7 +435,8 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
                              "k >= 1: weights from the counter RNG inside the SpMM, only kept entries gathered) incl. its long-row kernels")
     roof_b = roofline_record(n, nnz, C, ms_b * 1e-3, K, "train_backward_" + wl, measured_peak,
                              b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True), what="one backward TRAINING iteration "
-                             "(gnx_spmm_dropped over the transposed structure, the column scale gathered per kept entry) incl. its long-row kernels")
+                             "(gnx_spmm_dropped_back over the transposed structure: the running gradient sum updated and the next step's "
+                             "pre-scaled operand written in the epilogue) incl. its long-row kernels")
     out["training_step_C64"] = {"ms": ms, "two_pass_ms": ms2, "edges_per_s": 2 * nnz * K / ms * 1e3,
                                 "forward_launch_ms": ms_f, "backward_launch_ms": ms_b, "degree_scales_all_streams_ms": ms_d,
                                 "launches_share_of_step": (K * (ms_f + ms_b) + ms_d) / ms, "kept_entries": kept, "kernel": kernel_f,

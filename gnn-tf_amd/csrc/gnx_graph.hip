@@ -338,7 +338,8 @@ static void drop_transpose(gnx_graph *g) {
     if (g->t_vals) (void)hipFree(g->t_vals);
     if (g->t_raw) (void)hipFree(g->t_raw);
     if (g->t_rowidx) (void)hipFree(g->t_rowidx);
-    g->t_perm = nullptr; g->t_vals = nullptr; g->t_raw = nullptr; g->t_rowidx = nullptr;
+    if (g->t_mask) (void)hipFree(g->t_mask);
+    g->t_perm = nullptr; g->t_vals = nullptr; g->t_raw = nullptr; g->t_rowidx = nullptr; g->t_mask = nullptr;
     g->has_t = false;
 }
 
@@ -492,6 +493,7 @@ int gnx_graph_destroy(gnx_graph_t g) {
     if (g->t_vals) (void)hipFree(g->t_vals);
     if (g->t_raw) (void)hipFree(g->t_raw);
     if (g->t_rowidx) (void)hipFree(g->t_rowidx);
+    if (g->t_mask) (void)hipFree(g->t_mask);
     if (g->partial) (void)hipFree(g->partial);
     if (g->deg) (void)hipFree(g->deg);
     if (g->blk_col_gid) (void)hipFree(g->blk_col_gid);
@@ -514,6 +516,8 @@ int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream) {
         int rc = ensure_transpose(g, s);
         if (rc != GNX_OK) return rc;
         chunks = std::max(chunks, g->t.n_chunks);
+        if (!g->t_mask && !g->has_dups && g->t.nnz > 0)      // the keep-bit scratch of a training step's column sums
+            GNX_HIP(hipMalloc((void **)&g->t_mask, (size_t)g->t.nnz * sizeof(uint16_t)));
     }
     if ((flags & GNX_RESERVE_K_LOOP) && C <= RELABEL_MAX_C && g->a.n_rows == g->a.n_cols && g->a.n_rows >= (1 << 20) && g->a.nnz >= g->a.n_rows) {
         int rc = ensure_relabel(g, s);

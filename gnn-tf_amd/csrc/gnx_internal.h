@@ -48,9 +48,10 @@ constexpr int LONG_CHUNK = GNX_LONG_CHUNK;
 // 2^20 rows the plan therefore cuts rows at 128 entries into 128-entry chunks, and the sub-wave kernels take chunks and short rows in one launch.
 constexpr int SMALL_ROWS = 1 << 20;
 constexpr int TINY_ROWS = 1 << 15;      // below this everything is cache-resident and launch-bound: an extra reduce launch costs more than it saves
-// widest feature rows (floats) the K loop runs on the degree-relabelled copy of a large square graph: 32 floats = one 128-byte line
-// per gather; measured round 4 (RMAT 10M / 100M, K = 10): C = 32 22.8 -> 21.2 ms with the vertices in that order, C = 64 loses
-constexpr int RELABEL_MAX_C = 32;
+// widest feature rows (floats) the K loop runs on the degree-relabelled copy of a large square graph.  Measured round 4 (RMAT
+// 10M / 100M, K = 10) with the threshold at 32: C = 32 gains 7 % from the order and pays it back for the value permutation, the
+// H0 permutation and the scattered last iteration (22.77 vs 22.78 ms); C = 64 loses.  16 stays.
+constexpr int RELABEL_MAX_C = 16;
 constexpr int SMALL_LONG_ROW = GNX_LONG_ROW < 128 ? GNX_LONG_ROW : 128;
 
 // One CSR-like structure (the matrix itself, or its transpose).
@@ -88,6 +89,7 @@ struct gnx_graph {
     float *t_vals = nullptr;     // [a.nnz] scratch: values gathered into transposed order
     float *t_raw = nullptr;      // [a.nnz] raw values in transposed order (streaming column sums)
     int32_t *t_rowidx = nullptr; // [a.nnz] row of the transposed structure (= column of A) per transposed position
+    uint16_t *t_mask = nullptr;  // [a.nnz] scratch: keep bits of up to 16 dropout streams per transposed position (gnx_graph_colsum_streams)
     // partial slab for long rows (grown on demand)
     float *partial = nullptr;
     size_t partial_bytes = 0;
@@ -155,6 +157,8 @@ __device__ __forceinline__ float dropped_weight(const DropFuse &f, float raw, in
     const uint64_t stream = f.stream + (f.offset ? *f.offset : 0);
     const uint64_t kc = f.gid ? (uint64_t)f.gid[ac] : (uint64_t)ac;
     if (hash_u24(f.seed, stream, (uint64_t)(ar + f.row0_key), kc, 0) < f.thr) return 0.f;   // dropped: (D * 0) * D = 0 for finite scales
+    if (f.col_prescaled && f.transposed)          // the gathered row (vertex ar) carries D[ar] already: what is left is the OUTPUT row's scale
+        return (raw * f.scale) * f.D[ac];
     const float w = f.D[ar + f.row0_D] * (raw * f.scale);
     return f.col_prescaled ? w : w * f.D[ac];
 }
@@ -175,6 +179,12 @@ struct SpmmArgs {
     const int32_t *out_rows;   // optional destination row of every result row (gnx_spmm_scatter / gnx_spmm_rows)
     bool map_h0;               // H0 rows are indexed through out_rows as well (gnx_spmm_rows)
     const float *out_scale;    // optional per-row factor applied to the finished row (gnx_spmm_dropped_chained: the NEXT iteration's column scale)
+    // optional SECOND result of the same sums (gnx_spmm_dropped_back): out2[row] = acc * beta2 * (out2_scale ? out2_scale[row] : 1) --
+    // no mix term, no activation; `out` then carries the running gradient sum and out2 the pre-scaled operand of the next step
+    float *out2;
+    int64_t ldo2;
+    float beta2;
+    const float *out2_scale;
     int64_t n_rows;
     int64_t slot0;             // first row slot of this launch (a launch holds at most 2^32 work-items: huge graphs are dealt in pieces)
     int C;

@@ -161,6 +161,87 @@ __global__ __launch_bounds__(256) void k_colsum_long_multi(const int64_t *__rest
     }
 }
 
+// The same sums in TWO passes (training steps: K streams at once, gnx_graph_colsum_streams).  In the kernels above the hashes sit
+// inside a loop whose trip count differs from lane to lane (8 lanes per column, columns of every length in one wave): most of the
+// VALU time goes to lanes that have run out of entries (measured round 4: 5.5 ms for 8 streams over 10^8 entries, hash-bound).
+// Pass 1 hashes with EVERY lane busy -- one lane per transposed position, all streams of the batch, the keep bits packed into one
+// 16-bit word per entry; pass 2 is the column walk of k_colsum_short_multi with a 2-byte read where the hashes were.  Same lane
+// mapping, same order of additions, same reduction tree: bit for bit the sums of the kernels above.
+__global__ __launch_bounds__(256) void k_keep_masks(const int32_t *__restrict__ t_rowidx /* column of A */, const int32_t *__restrict__ t_colidx /* row of A */,
+                                                    int64_t nnz, Drop d, int ns, uint16_t *__restrict__ mask) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const uint64_t row = key_row(d, t_colidx[p]), kc = key_col(d, t_rowidx[p]);
+    const uint64_t stream = stream_of(d);
+    uint32_t bits = 0;
+#pragma unroll 2
+    for (int s = 0; s < ns; ++s) bits |= (hash_u24(d.seed, stream + s, row, kc, 0) >= d.thr ? 1u : 0u) << s;
+    mask[p] = (uint16_t)bits;
+}
+
+template <int NS>
+__global__ void k_colsum_short_masked(const int64_t *__restrict__ t_rowptr, const float *__restrict__ t_raw, const uint16_t *__restrict__ mask,
+                                      float scale, int ns, int64_t n_cols, int long_row, float *__restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t j = gid >> 3;
+    const int sub = (int)(gid & 7);
+    float acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+    bool is_long = false;
+    if (j < n_cols) {
+        const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
+        is_long = (e - b) > long_row;
+        if (!is_long) {
+            for (int64_t p = b + sub; p < e; p += 8) {
+                const float v = t_raw[p] * scale;
+                const uint32_t m = mask[p];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) acc[s] += ((m >> s) & 1u) ? v : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float a = acc[s];
+        a += __shfl_xor(a, 4);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 1);
+        if (j < n_cols && sub == 0 && !is_long && s < ns) out[(int64_t)s * n_cols + j] = a;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_colsum_long_masked(const int64_t *__restrict__ t_rowptr, const float *__restrict__ t_raw,
+                                                            const uint16_t *__restrict__ mask, float scale, int ns,
+                                                            const int32_t *__restrict__ long_rows, int64_t n_cols, float *__restrict__ out) {
+    __shared__ float red[256];
+    const int32_t j = long_rows[blockIdx.x];
+    const int64_t b = t_rowptr[j], e = t_rowptr[j + 1];
+    float acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.f;
+    for (int64_t p = b + threadIdx.x; p < e; p += 256) {
+        const float v = t_raw[p] * scale;
+        const uint32_t m = mask[p];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] += ((m >> s) & 1u) ? v : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s < ns) {                                                // (block-uniform)
+            __syncthreads();
+            red[threadIdx.x] = acc[s];
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) out[(int64_t)s * n_cols + j] = red[0];
+        }
+    }
+}
+
 // gnn.py:41 / :44 with optional "+I before" folded in as +1 on every column sum
 __global__ void k_degree_scale(float *__restrict__ d, int64_t n, int normalized, float eye) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,25 +371,50 @@ int gnx_graph_colsum_streams(gnx_graph_t g, float dropout_p, uint64_t seed, uint
     const Csr &t = g->t;
     if (t.n_rows == 0) return GNX_OK;
     const unsigned nb = blocks_for(t.n_rows * 8);
-    for (int k0 = 0; k0 < n_streams;) {                 // batches of 8 / 4 / 2 / 1 streams per pass
+    if (n_streams >= 2 && t.nnz > 0) {
+        // two passes per batch of up to 16 streams: keep bits with every lane busy, then the column walk over 2-byte masks
+        if (!g->t_mask) {
+            if (stream_is_capturing(s)) {
+                set_error("gnx_graph_colsum_streams: the keep-bit scratch of this handle would have to be allocated while the stream is being "
+                          "captured: call gnx_graph_reserve(handle, C, GNX_RESERVE_TRANSPOSED) or run the call once eagerly before capturing");
+                return GNX_ERR_UNSUPPORTED;
+            }
+            GNX_HIP(hipMalloc((void **)&g->t_mask, (size_t)t.nnz * sizeof(uint16_t)));
+        }
+        for (int k0 = 0; k0 < n_streams; k0 += 16) {
+            const int ns = n_streams - k0 < 16 ? n_streams - k0 : 16;
+            Drop d;
+            rc = make_drop(g, dropout_p, seed, first_stream + k0, d);
+            if (rc != GNX_OK) return rc;
+            float *out = d_colsum_out + (int64_t)k0 * n;
+            hipLaunchKernelGGL(k_keep_masks, dim3(blocks_for(t.nnz)), dim3(256), 0, s, g->t_rowidx, t.colidx, t.nnz, d, ns, g->t_mask);
+#define GNX_MASKED(NS)                                                                                                                 \
+            do {                                                                                                                       \
+                hipLaunchKernelGGL(k_colsum_short_masked<NS>, dim3(nb), dim3(256), 0, s, t.rowptr, g->t_raw, g->t_mask, d.scale, ns,  \
+                                   t.n_rows, t.long_row, out);                                                                         \
+                if (t.n_long > 0)                                                                                                      \
+                    hipLaunchKernelGGL(k_colsum_long_masked<NS>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, g->t_raw,        \
+                                       g->t_mask, d.scale, ns, t.long_rows, t.n_rows, out);                                            \
+            } while (0)
+            if (ns > 8) GNX_MASKED(16);
+            else if (ns > 4) GNX_MASKED(8);
+            else if (ns > 2) GNX_MASKED(4);
+            else GNX_MASKED(2);
+#undef GNX_MASKED
+        }
+        GNX_HIP(hipGetLastError());
+        return GNX_OK;
+    }
+    for (int k0 = 0; k0 < n_streams;) {                 // one stream: a single pass
         Drop d;
         rc = make_drop(g, dropout_p, seed, first_stream + k0, d);
         if (rc != GNX_OK) return rc;
         float *out = d_colsum_out + (int64_t)k0 * n;
-        const int left = n_streams - k0;
-#define GNX_MULTI(NS)                                                                                                                  \
-        do {                                                                                                                           \
-            hipLaunchKernelGGL(k_colsum_short_multi<NS>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, t.n_rows, t.long_row, out); \
-            if (t.n_long > 0)                                                                                                          \
-                hipLaunchKernelGGL(k_colsum_long_multi<NS>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, \
-                                   t.long_rows, t.n_rows, out);                                                                        \
-            k0 += NS;                                                                                                                  \
-        } while (0)
-        if (left >= 8) GNX_MULTI(8);
-        else if (left >= 4) GNX_MULTI(4);
-        else if (left >= 2) GNX_MULTI(2);
-        else GNX_MULTI(1);
-#undef GNX_MULTI
+        hipLaunchKernelGGL(k_colsum_short_multi<1>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d, t.n_rows, t.long_row, out);
+        if (t.n_long > 0)
+            hipLaunchKernelGGL(k_colsum_long_multi<1>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_raw, d,
+                               t.long_rows, t.n_rows, out);
+        k0 += 1;
     }
     GNX_HIP(hipGetLastError());
     return GNX_OK;

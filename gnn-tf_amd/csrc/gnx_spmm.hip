@@ -171,6 +171,13 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = fmaf(d, xr[v], acc[v]);
     }
+    if (p.out2) {                                  // second result of the same sums (see SpmmArgs::out2)
+        const float f2 = p.out2_scale ? p.out2_scale[row] : 1.f;
+        float o2[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o2[v] = (acc[v] * p.beta2) * f2;
+        vstore<VEC>(p.out2 + row * p.ldo2 + c, o2);
+    }
     float o[VEC];
     const int64_t orow = p.out_rows ? (int64_t)p.out_rows[row] : row;
     if (p.H0) {
@@ -1423,6 +1430,38 @@ int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, u
     p.fuse.col_prescaled = x_prescaled ? 1 : 0;
     p.fuse.row0_key = g->blk_row0_global; p.fuse.row0_D = g->blk_row0_buf; p.fuse.gid = g->blk_col_gid;
     return launch_spmm(g, g->a, p, (hipStream_t)stream);
+}
+
+int gnx_spmm_dropped_back(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int x_prescaled,
+                          const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_S_in, int64_t lds_in,
+                          float s_alpha, float s_beta, float *d_S_out, int64_t lds_out, float y_beta, float *d_Y_out, int64_t ldy,
+                          void *stream) {
+    int rc = check_common("gnx_spmm_dropped_back", g, d_X, ldx, C, d_S_in, lds_in, d_S_out, lds_out);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(d_D != nullptr && d_S_in != nullptr, "gnx_spmm_dropped_back: NULL degree scales / running sum");
+    GNX_CHECK_ARG(d_Y_out == nullptr || (ldy >= C && (const void *)d_Y_out != (const void *)d_X && (const void *)d_Y_out != (const void *)d_S_out
+                                         && (const void *)d_Y_out != (const void *)d_S_in),
+                  "gnx_spmm_dropped_back: the pre-scaled output needs a buffer of its own");
+    GNX_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout rate %g outside [0, 1)", (double)dropout_p);
+    GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols && g->blk_col_gid == nullptr, "gnx_spmm_dropped_back: needs a square stand-alone graph");
+    if (g->has_dups) {
+        set_error("gnx_spmm_dropped_back: the graph holds duplicate COO entries");
+        return GNX_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_transpose(g, s);
+    if (rc != GNX_OK) return rc;
+    SpmmArgs p{};
+    p.vals = g->t_raw;
+    p.X = d_X; p.ldx = ldx; p.H0 = d_S_in; p.ldh0 = lds_in; p.beta = s_beta; p.alpha = s_alpha; p.act = GNX_ACT_NONE;
+    p.out = d_S_out; p.ldo = lds_out; p.C = (int)C;
+    p.out2 = d_Y_out; p.ldo2 = ldy; p.beta2 = y_beta; p.out2_scale = d_Y_out ? d_D_next : nullptr;
+    p.fuse.D = d_D; p.fuse.seed = seed; p.fuse.stream = stream_id; p.fuse.offset = g->stream_offset;
+    p.fuse.thr = (uint32_t)((double)dropout_p * 16777216.0);
+    p.fuse.scale = 1.0f / (1.0f - dropout_p);
+    p.fuse.transposed = 1;
+    p.fuse.col_prescaled = x_prescaled ? 1 : 0;
+    return launch_spmm(g, g->t, p, s);
 }
 
 int gnx_graph_permute_values_t(gnx_graph_t g, const float *d_vals, float *d_vals_t_out, void *stream) {

@@ -316,6 +316,39 @@ def _launch_chained(adj: "DroppedAdjacency", X, H0, beta, alpha, prescaled, D_ne
     return out
 
 
+def _launch_back(adj: "DroppedAdjacency", X, prescaled, D_next, S_in, s_alpha, s_beta, S_out, y_beta, Y_out):
+    """One backward training iteration inside a loop (gnx_spmm_dropped_back): acc = A_k^T X over the transposed structure, weights
+    made in the kernel; S_out = s_beta acc + s_alpha S_in (S_in may be S_out), Y_out = y_beta acc * D_next (skipped when None)."""
+    g = adj.graph
+    nat.require_cuda(X, S_in, S_out)
+    _same_device(g, X, S_in, S_out, Y_out, adj.D, D_next)
+    C = X.shape[1]
+    if any(t is not None and (tuple(t.shape) != (g.n_rows, C) or not t.is_contiguous() or t.dtype != torch.float32) for t in (X, S_in, S_out, Y_out)):
+        raise Exception("chained backward: bad operand shapes")
+    with nat.on_device(X.device):
+        nat.check(nat.lib().gnx_spmm_dropped_back(g.handle, nat.ptr(adj.D), adj.p, adj.seed, adj.stream_id, 1 if prescaled else 0, nat.ptr(D_next),
+                                                  nat.ptr(X), C, C, nat.ptr(S_in), C, float(s_alpha), float(s_beta), nat.ptr(S_out), C,
+                                                  float(y_beta), nat.ptr(Y_out), C, nat.current_stream()))
+
+
+def _backward_chained(adjs, g, a):
+    """dH0 of K chained training iterations for the upstream gradient ``g``: g_k = (1-a) A_k^T g_{k+1}, dH0 = g_0 + a (g_1 + ... +
+    g_K), as K calls of gnx_spmm_dropped_back -- every call adds its g_k to the running sum in its epilogue and hands the next call
+    its operand pre-scaled by that call's column scale, so no gradient of an iteration is kept, no per-entry scale is gathered
+    and no separate summation pass exists."""
+    K = len(adjs)
+    g = _as_f32_rows(g).contiguous()
+    S = torch.empty_like(g)
+    X = g
+    for k in range(K - 1, -1, -1):
+        first, last = k == K - 1, k == 0
+        Y = None if last else torch.empty_like(g)
+        _launch_back(adjs[k], X, not first, None if last else adjs[k - 1].D, g if first else S, a if first else 1.0,
+                     (1.0 - a) if last else a * (1.0 - a), S, 1.0 - a, Y)
+        X = Y
+    return S
+
+
 def launch_rows(adj: Adjacency, X, H0, beta, alpha, rows, out, act=nat.ACT_NONE):
     """The fused step over a graph that holds a SUBSET of the output rows (the interior or the boundary rows of
     a vertex block): result row r is written to out[rows[r]] and mixes in H0[rows[r]] (gnx_spmm_rows)."""
@@ -419,6 +452,7 @@ class _PPRLoop(torch.autograd.Function):
             # the rows, so from k = 1 on no per-entry scale gather is left (gnx_spmm_dropped_chained)
             adjs = [first] + [make_adj(k, False) for k in range(1, K)]
             chained = all(isinstance(adj, DroppedAdjacency) and adj.graph is first.graph for adj in adjs)
+            ctx.chained = chained and first.graph.n_rows == first.graph.n_cols
             for k, adj in enumerate(adjs):
                 if chained:
                     H = _launch_chained(adj, H, H0, 1.0 - a, a, prescaled=k > 0, D_next=adjs[k + 1].D if k + 1 < K else None)
@@ -434,6 +468,11 @@ class _PPRLoop(torch.autograd.Function):
         # dH0 = g_0 + a (g_1 + ... + g_K): the gradients of the iterations are KEPT (as many as a tenth of the card's memory
         # holds, at most 15) and added up by one pass (gnx_linear_combination) instead of a read-modify-write of dH0 per iteration
         g = _padded(g.contiguous(), friendly_width(ctx.C, g.shape[0]))
+        if getattr(ctx, "chained", False):
+            adjs = [ctx.make_adj(k, True) for k in range(ctx.K)]
+            if all(isinstance(adj, DroppedAdjacency) for adj in adjs):
+                gH0 = _backward_chained(adjs, g, ctx.a)
+                return (gH0 if gH0.shape[1] == ctx.C else gH0[:, :ctx.C].contiguous()), None, None, None
         room = int(0.1 * torch.cuda.get_device_properties(g.device).total_memory) // max(g.numel() * 4, 1)
         limit = max(2, min(LINCOMB_TERMS - 1, room))
         pending, total = [], None

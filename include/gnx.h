@@ -213,6 +213,23 @@ int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, u
                              const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_H0, int64_t ldh0,
                              float beta, float alpha, int act, float *d_out, int64_t ldo, void *stream);
 
+/* One BACKWARD training iteration inside a loop -- what tf.GradientTape derives for K PPRIteration layers (trainable.py:70-78 over
+ * filter.py:19-21): g_k = (1-a) A_k^T g_{k+1}, dH0 = g_0 + a (g_1 + ... + g_K).  Walks the TRANSPOSED structure with the weights
+ * of dropout stream `stream_id` made inside the kernel, acc[r] = sum_c A_k[c][r] X[c], and writes TWO results:
+ *     S_out[r] = s_beta * acc[r] + s_alpha * S_in[r]          the running sum dH0 is built in (S_in may be S_out: in place)
+ *     Y_out[r] = y_beta * acc[r] * D_next[r]                  g_k carrying the column scale of the NEXT step (stream_id - 1), or
+ *                                                             plain when d_D_next is NULL; skipped when d_Y_out is NULL
+ * With x_prescaled the rows of X carry their own scale D[c] already (the previous call's Y_out), so no per-entry gather of a
+ * column scale is left -- in the un-chained form (gnx_spmm_dropped, transposed) that gather fetches a 128-byte line per kept
+ * entry (profiles/NOTES.md round 4: +4.5 GB per launch at config 4, C = 64).  The loop: X = upstream gradient, S_in = X,
+ * s_alpha = a for the first call; afterwards X = the previous Y_out, S_in = S_out, s_alpha = 1; s_beta = a (1-a), y_beta = 1-a;
+ * the last call (stream 0) adds g_0 whole: s_beta = 1-a, no Y_out.  Square stand-alone graphs without duplicate entries.
+ * Finite operands only (a dropped entry's row is not gathered), as for gnx_spmm_dropped. */
+int gnx_spmm_dropped_back(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int x_prescaled,
+                          const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_S_in, int64_t lds_in,
+                          float s_alpha, float s_beta, float *d_S_out, int64_t lds_out, float y_beta, float *d_Y_out, int64_t ldy,
+                          void *stream);
+
 /* gnx_spmm_rows: the fused step for a handle that holds only a SUBSET of the output rows (the interior or the
  * boundary rows of a vertex block, compacted): result row r lands in out[d_rows[r], :] and mixes in
  * H0[d_rows[r], :] (d_rows int32 [n_rows of the handle]; out and H0 are the full-height matrices).  Same
@@ -232,7 +249,7 @@ int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const 
  * d_out, d_work and d_H0 must be distinct buffers.  Two things the loop does that K separate gnx_ppr_step calls do not:
  *   - rows without stored entries (a * H0 after every iteration) are computed when each buffer is first a destination and left
  *     alone afterwards (GNX_ACT_SKIP_EMPTY) -- same bits, fewer bytes;
- *   - for C <= 32 on graphs of at least 2^20 vertices (no diagonal) the iterations run on a degree-relabelled copy of the
+ *   - for C <= 16 on graphs of at least 2^20 vertices (no diagonal) the iterations run on a degree-relabelled copy of the
  *     matrix (heaviest vertices first; inside a degree bin the vertices follow their most popular neighbour's rank) that the
  *     handle builds on first use (+ about 12 bytes per entry and an [n, C] scratch, owned by the handle): H0 is
  *     permuted on the way in, the last iteration scatters back into the caller's row order; a row's columns are then summed in

@@ -56,7 +56,7 @@ def test_a_fraction_above_one_is_never_printed(traffic_table):
 def test_training_iteration_byte_model():
     n, nnz, kept, C = 1000, 20000, 9000, 64
     assert bench.alg_bytes_dropped_iteration(n, nnz, kept, C) == nnz * 8 + kept * 256 + n * (12 + 512)
-    assert bench.alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True) == nnz * 8 + kept * 260 + n * (8 + 256)
+    assert bench.alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True) == nnz * 8 + kept * 256 + n * (12 + 768)
     # nothing dropped: the forward iteration moves what an eval iteration moves plus the two scale vectors
     assert bench.alg_bytes_dropped_iteration(n, nnz, nnz, C) == bench.alg_bytes_per_iteration(n, nnz, C) + 8 * n
 

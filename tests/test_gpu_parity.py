@@ -223,9 +223,9 @@ def test_k_loop_skips_settled_empty_rows_bitwise(gnntf):
 
 
 def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
-    """gnx_appnp_propagate at C <= 32 on a large graph runs on the degree-relabelled copy of the matrix (H0 permuted in, the last
+    """gnx_appnp_propagate at C <= 16 on a large graph runs on the degree-relabelled copy of the matrix (H0 permuted in, the last
     iteration scattered back): same result as K plain steps up to float32 rounding (the columns of a row are summed in another
-    order), for every K parity, unaligned widths, weighted directed patterns and empty rows; C > 32 keeps the plain path bitwise."""
+    order), for every K parity, unaligned widths, weighted directed patterns and empty rows; C > 16 keeps the plain path bitwise."""
     n = 1_200_000
     gen = torch.Generator(device="cuda").manual_seed(5)
     rows = (torch.rand(6_000_000, device="cuda", generator=gen) ** 3 * (n * 0.7)).long()          # skewed; rows above 0.7 n stay empty
@@ -241,7 +241,7 @@ def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
             for _ in range(K):
                 H = gnntf.ppr_step(adj, H, H0, 0.15)
             got = gnntf.appnp_propagate(adj, H0, a=0.15, iterations=K)
-            if C > 32:
+            if C > 16:
                 assert torch.equal(got, H)
             else:
                 assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
@@ -537,7 +537,7 @@ def test_degree_scales_of_k_streams_in_one_pass(gnntf):
     for with_dups in (False, True):
         c, v = (np.concatenate([coo, coo[:40]]), np.concatenate([vals, vals[:40]])) if with_dups else (coo, vals)
         g = make_graph(gnntf, c, v, shape)
-        for K in (1, 3, 10, 13):
+        for K in (1, 3, 10, 13, 20):
             got = torch.empty((K, n), device="cuda")
             nat.check(nat.lib().gnx_graph_colsum_streams(g.handle, 0.5, 99, 7, K, nat.ptr(got), nat.current_stream()))
             for k in range(K):
@@ -783,12 +783,12 @@ def test_capture_needs_the_handle_prepared_and_reserve_prepares_it(gnntf):
         with torch.cuda.graph(refused):
             gnntf.spmm(adj, X64)
     torch.cuda.synchronize()
-    with pytest.raises(Exception, match="gnx_graph_reserve"):           # the transposed structure does not exist yet either
+    fresh = make_graph(gnntf, coo, vals, shape)                         # a handle nothing has used yet: no transposed structure
+    with pytest.raises(Exception, match="gnx_graph_reserve"):
         with torch.cuda.graph(torch.cuda.CUDAGraph()):
-            gnntf.sparse._launch(adj, X8, None, 1.0, 0.0, 0, transposed=True)
+            gnntf.sparse._launch(gnntf.Adjacency(fresh, None), X8, None, 1.0, 0.0, 0, transposed=True)
     torch.cuda.synchronize()
     g.reserve(64, transposed=True)
-    want_f = None
     recorded = torch.cuda.CUDAGraph()
     with torch.cuda.graph(recorded):
         out_f = gnntf.spmm(adj, X64)                        # first launch at the widest width: inside the capture
@@ -1019,6 +1019,53 @@ def test_chained_training_forward_equals_step_loop(gnntf, C):
     for ai, av in adjs:
         ref = orc.ppr_iteration(ai, av, shape, ref, H0.cpu().numpy().astype(np.float64), a)
     np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
+
+
+@pytest.mark.parametrize("C", [7, 16, 64])
+def test_chained_training_backward_equals_step_loop(gnntf, C):
+    """gnx_spmm_dropped_back: the backward of the fused training loop as K launches that each add their g_k to the running sum
+    dH0 = g_0 + a (g_1 + ... + g_K) and hand the next launch its operand pre-scaled (no kept gradients, no per-entry scale gather,
+    no summation pass).  Same value as K un-chained transposed launches (gnx_spmm_dropped) followed by the explicit sum, up to
+    float32 rounding, and as the float64 oracle through the dropped adjacencies -- hub rows, isolated vertices (scale 0: their
+    pre-scaled rows are zero and never gathered), a weighted value-asymmetric matrix, and autograd through ppr_loop."""
+    from gnntf import sparse
+    from gnntf.sparse import _launch
+    n, K, a, p_drop, seed, first = 2500, 5, 0.1, 0.5, 9, 4
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, 30000, seed=11)
+    hub = np.random.default_rng(1).choice(np.arange(1, n), size=1300, replace=False)
+    coo = np.unique(np.concatenate([coo, np.stack([np.zeros_like(hub), hub], 1), np.stack([hub, np.zeros_like(hub)], 1)]), axis=0)
+    vals = (np.random.default_rng(2).random(len(coo)) + 0.5).astype(np.float32)
+    g = make_graph(gnntf, coo, vals, shape)
+    up = dev(np.random.default_rng(C).standard_normal((n, C)).astype(np.float32))
+    D = sparse.dropped_degree_scales(g, p_drop, seed, first, K)
+    adjs = [sparse.dropped_adjacency(g, p_drop, seed, first + k, D=D[k]) for k in range(K)]
+    got = sparse._backward_chained(adjs, up, a)
+    assert g.last_kernel().endswith("_drop")
+    gk, want = up, up * a
+    for k in range(K - 1, -1, -1):
+        gk = _launch(adjs[k], gk, None, 1.0 - a, 0.0, 0, transposed=True)
+        want = want + gk * (a if k >= 1 else 1.0)
+    scale = want.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)
+    assert ((got - want).abs() / scale).max().item() < 2e-5
+    # float64 oracle: g_k = (1-a) A_k^T g_{k+1} through the materialised dropped adjacencies
+    ref_g = up.cpu().numpy().astype(np.float64)
+    ref = a * ref_g
+    import scipy.sparse as sp
+    for k in range(K - 1, -1, -1):
+        ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=p_drop, training=True, seed=seed, stream=first + k, dtype=np.float64)
+        A = sp.csr_matrix((av, (ai[:, 0], ai[:, 1])), shape=shape)
+        ref_g = (1.0 - a) * (A.T @ ref_g)
+        ref = ref + ref_g * (a if k >= 1 else 1.0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL, atol=1e-4)
+    # and it is what autograd runs for the fused loop
+    H0 = dev(np.random.default_rng(3).standard_normal((n, C)).astype(np.float32)).requires_grad_()
+    make = lambda k, bwd=False: adjs[k]
+    sparse.ppr_loop(make, H0, a, K).backward(up)
+    Cp = sparse.friendly_width(C, n)
+    if Cp == C:
+        assert torch.equal(H0.grad, got)
+    else:
+        assert ((H0.grad - got).abs() / scale).max().item() < 2e-5
 
 
 @pytest.mark.parametrize("n", [4, 4 * 1024 * 4 * 3, 4 * (1024 * 4 * 1024 * 2 + 12345), 4 * 999_983])

@@ -9,7 +9,7 @@ The run is cut into SEGMENTS by a marker kernel (k_stream, a 64-float gnx_stream
 profiles/summarize_train.py can tell the forward launches from the backward ones (same kernel names on a symmetric graph):
 
     warm-up | MARK | ``launches`` forward iterations (gnx_spmm_dropped_chained, k >= 1) | MARK | ``launches`` backward iterations
-    (gnx_spmm_dropped, transposed) | MARK | 3 x the degree scales of all K streams (gnx_graph_colsum_streams) | MARK | ``steps``
+    (gnx_spmm_dropped_back, a middle iteration) | MARK | 3 x the degree scales of all K streams (gnx_graph_colsum_streams) | MARK | ``steps``
     whole steps | MARK
 
 Prints one JSON line: ms per launch / step by events, entries kept per dropout stream, the byte model (bench.alg_bytes_dropped_*)."""
@@ -72,13 +72,15 @@ def main():
     adj1 = sparse.dropped_adjacency(g, 0.5, 1, 1, D=scales[1])
     with torch.no_grad():
         sparse._launch_chained(adj1, X, X, 0.9, 0.1, True, scales[2])
-        sparse._launch(adj1, gout, None, 0.9, 0.0, nat.ACT_NONE, transposed=True)
+        S_run, Y_run = torch.zeros_like(gout), torch.empty_like(gout)
+        back = lambda: sparse._launch_back(adj1, gout, True, scales[0], S_run, 1.0, 0.09, S_run, 0.9, Y_run)
+        back()
         torch.cuda.synchronize()
         mark()
         res["forward_launch_ms"] = timed(lambda: sparse._launch_chained(adj1, X, X, 0.9, 0.1, True, scales[2]), a.launches)
         res["kernel"] = g.last_kernel()
         mark()
-        res["backward_launch_ms"] = timed(lambda: sparse._launch(adj1, gout, None, 0.9, 0.0, nat.ACT_NONE, transposed=True), a.launches)
+        res["backward_launch_ms"] = timed(back, a.launches)
         mark()
         res["degree_scales_all_streams_ms"] = timed(lambda: sparse.dropped_degree_scales(g, 0.5, 1, 0, K), 3)
         mark()
