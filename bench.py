@@ -347,6 +347,7 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         F = 64
         X = torch.randn(n, F, device=device)
         model = gnntf.APPNP(g, X, num_classes=C, latent_dims=[], iterations=K, a=a)
+        model.reset()                                            # variables are zero until reset() (variables.py:62-66; train() calls it)
         model.training_mode(False)
         nodes = torch.randperm(n, device=device)[:100_000]
         task = gnntf.NodeClassification(nodes)
@@ -380,6 +381,7 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         H0l = hand.add(gnntf.Dense(C, regularize=False))
         for _ in range(K):
             hand.add(gnntf.PPRIteration(H0l, a))
+        hand.reset()
         hand.training_mode(False)
         with torch.no_grad():
             t_hand = median_ms(lambda: hand(hand.features), reps=3, warm=1)
@@ -877,7 +879,9 @@ def main():
             roof = roofline_record(n_local, nnz_local, C, launch_s, K, name, measured_peak)
         else:                                                       # this rank's block: kernels alone (no exchange beside them)
             t_c = halo["compute_ms_alone"] * 1e-3 if world > 1 else sg.time_compute(state, a)
-            roof = roofline_record(n_local, nnz_local, C_local, t_c, K, name + f"_block_of_{pv}", measured_peak)
+            # (the block's committed PMC passes are per plan: tools/sim_blocks.py --pmc-iterations under rocprofv3, profiles/summarize_blocks.py)
+            block_name = name + f"_block_of_{pv}_{halo['cover']}_chunks{halo['chunks']}"
+            roof = roofline_record(n_local, nnz_local, C_local, t_c, K, block_name, measured_peak)
             roof["note"] = "rank 0's vertex block, one iteration's kernels alone (pack + SpMM of every column chunk; no exchange beside them); " + roof["note"]
         result = {
             "metric": f"propagated edges/sec (APPNP K={K})", "value": edges / elapsed, "unit": "edges/s",

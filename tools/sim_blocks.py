@@ -143,6 +143,10 @@ def main():
                     help="loop-back exchange by device copies (copy), through RCCL send / recv pairs of a one-rank group (rccl), or emulated "
                          "link time without traffic (sleep:GBs -- per link and direction)")
     ap.add_argument("--lane-skip", type=int, default=0, help="streams created (and kept) before the exchange lane's: moves the lane to another hardware queue")
+    ap.add_argument("--pmc-iterations", type=int, default=0,
+                    help="for rocprofv3 --pmc passes: run ONLY this many kernels-alone iterations (what bench.py times as compute_ms_alone: "
+                         "SpMM of the interior and boundary rows + pack, every column chunk) between two marker launches (k_stream), print "
+                         "the plan sizes and stop -- profiles/summarize_blocks.py turns the passes into the block's pmc_traffic.json entry")
     a = ap.parse_args()
     if a.transport == "rccl":
         import torch.distributed as dist
@@ -181,6 +185,19 @@ def main():
     C = a.feats
     H0 = torch.rand(sg.n_local, C, device=dev) * 2 - 1
     state = sg.make_state(H0)
+    if a.pmc_iterations > 0:
+        from gnntf import _native as nat
+        src, sink = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        mark = lambda: nat.check(nat.lib().gnx_stream_read(nat.ptr(src), 64, nat.ptr(sink), nat.current_stream()))
+        sg.time_compute(state, 0.1, repeats=0)                          # warm-up: slabs, lazy structures
+        torch.cuda.synchronize()
+        mark()
+        t_c = sg.time_compute(state, 0.1, repeats=a.pmc_iterations - 1)
+        mark()
+        torch.cuda.synchronize()
+        print(json.dumps({"world": P, "rank": r, "cover": a.cover, "chunks": a.chunks, "iterations_between_markers": a.pmc_iterations,
+                          "kernels_ms_per_iteration": t_c * 1e3, "rows": sg.n_local, "entries": sg.nnz_local, "features": C, "stats": sg.stats}))
+        return
     t_c = sg.time_compute(state, 0.1)
     t_x = sg.time_exchange(state)                                       # loop-back copies: local HBM traffic only
 
