@@ -891,7 +891,9 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_wave_drop(const SpmmArgs p) {
     }
 }
 
-template <int VEC, int G, int U>
+// PIPE: the (col, raw value) pair a lane owns in the NEXT round is loaded before this round's kept entries are gathered, so a row
+// of more than G entries pays the index latency once instead of once per round.
+template <int VEC, int G, int U, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
@@ -907,11 +909,19 @@ __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        int ncol = 0;
+        float nraw = 0.f;
+        if (PIPE && beg + sub < end) { ncol = p.colidx[beg + sub]; nraw = p.vals[beg + sub]; }
         for (int64_t base = beg; base < end; base += G) {          // G entries per round: lane `sub` owns entry base + sub
             const int n = (int)((end - base) < G ? (end - base) : G);
             int mycol = 0;
             float myw = 0.f;
-            if (sub < n) {
+            if (PIPE) {
+                const int ccol = ncol;
+                const float craw = nraw;
+                if (base + G + sub < end) { ncol = p.colidx[base + G + sub]; nraw = p.vals[base + G + sub]; }
+                if (sub < n) { mycol = ccol; myw = dropped_weight(p.fuse, craw, row, ccol); }
+            } else if (sub < n) {
                 mycol = p.colidx[base + sub];
                 myw = dropped_weight(p.fuse, p.vals[base + sub], row, mycol);
             }
@@ -1221,6 +1231,9 @@ void launch_long(const SpmmArgs &p, hipStream_t s) {
     GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
 }
 
+[[maybe_unused]] constexpr bool DROP_U8 = false, DROP_PIPE = false;     // product defaults of the training row kernels (see launch_rows_drop)
+constexpr int DROP_LONG_U = 4;
+
 template <int VEC>
 const char *launch_rows_drop(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
@@ -1229,10 +1242,25 @@ const char *launch_rows_drop(const SpmmArgs &p, hipStream_t s) {
         else                 GNX_ROW_PIECES((k_spmm_wave_drop<VEC, 8, 4>), 4, 256);
         return "spmm_wave_drop";
     }
-    if (lanes > 16) { GNX_ROW_PIECES((k_spmm_group_drop<VEC, 32, 4>), 8, 256); return "spmm_group32_drop"; }
-    if (lanes > 8)  { GNX_ROW_PIECES((k_spmm_group_drop<VEC, 16, 4>), 16, 256); return "spmm_group16_drop"; }
-    if (lanes > 4)  { GNX_ROW_PIECES((k_spmm_group_drop<VEC, 8, 4>), 32, 256); return "spmm_group8_drop"; }
-    GNX_ROW_PIECES((k_spmm_group_drop<VEC, 4, 4>), 64, 256);
+    // U gathers in flight per lane and the index prefetch: round-4 A/B on the config-4 graph (tuning build bits 1 << 17 = U 8,
+    // 1 << 19 = PIPE; profiles/NOTES.md)
+#ifdef GNX_TUNING
+    const bool u8 = (p.tune & (1 << 17)) != 0, pipe = (p.tune & (1 << 19)) != 0;
+#else
+    const bool u8 = DROP_U8, pipe = DROP_PIPE;
+#endif
+#define GNX_DROP_ROWS(G, RPB)                                                                                         \
+    do {                                                                                                              \
+        if (u8 && pipe)  GNX_ROW_PIECES((k_spmm_group_drop<VEC, G, 8, true>), RPB, 256);                              \
+        else if (u8)     GNX_ROW_PIECES((k_spmm_group_drop<VEC, G, 8, false>), RPB, 256);                             \
+        else if (pipe)   GNX_ROW_PIECES((k_spmm_group_drop<VEC, G, 4, true>), RPB, 256);                              \
+        else             GNX_ROW_PIECES((k_spmm_group_drop<VEC, G, 4, false>), RPB, 256);                             \
+    } while (0)
+    if (lanes > 16) { GNX_DROP_ROWS(32, 8); return "spmm_group32_drop"; }
+    if (lanes > 8)  { GNX_DROP_ROWS(16, 16); return "spmm_group16_drop"; }
+    if (lanes > 4)  { GNX_DROP_ROWS(8, 32); return "spmm_group8_drop"; }
+    GNX_DROP_ROWS(4, 64);
+#undef GNX_DROP_ROWS
     return "spmm_group4_drop";
 }
 
@@ -1240,9 +1268,17 @@ template <int VEC>
 void launch_long_drop(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
     if (lanes > 32)      GNX_LAUNCH((k_spmm_long_partial_drop<VEC, 8>), blocks_for(p.n_chunks, 4), p);
-    else if (lanes > 16) GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 32, 4>), blocks_for(p.n_chunks, 4), p);
-    else if (lanes > 8)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 16, 4>), blocks_for(p.n_chunks, 4), p);
-    else if (lanes > 4)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 8, 4>), blocks_for(p.n_chunks, 4), p);
+#ifdef GNX_TUNING
+    else if (p.tune & (1 << 18)) {
+        if (lanes > 16)      GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 32, 8>), blocks_for(p.n_chunks, 4), p);
+        else if (lanes > 8)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 16, 8>), blocks_for(p.n_chunks, 4), p);
+        else if (lanes > 4)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 8, 8>), blocks_for(p.n_chunks, 4), p);
+        else                 GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 4, 4>), blocks_for(p.n_chunks, 4), p);
+    }
+#endif
+    else if (lanes > 16) GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 32, DROP_LONG_U>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 8)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 16, DROP_LONG_U>), blocks_for(p.n_chunks, 4), p);
+    else if (lanes > 4)  GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 8, DROP_LONG_U>), blocks_for(p.n_chunks, 4), p);
     else                 GNX_LAUNCH((k_spmm_long_partial_group_drop<VEC, 4, 4>), blocks_for(p.n_chunks, 4), p);
     GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);
 }
