@@ -50,6 +50,9 @@ def parse():
                     help="N > 1: wall-clock budget of the variant selection before the timed region; what does not fit is recorded as skipped")
     ap.add_argument("--overlap-probe", choices=["on", "off"], default="on",
                     help="N > 1: probe where the exchange runs beside the compute stream (Comm.tune_overlap; GNX_TUNE_OVERLAP=0 also disables it)")
+    ap.add_argument("--pmc-in-run", choices=["on", "off"], default="on",
+                    help="N = 1: before anything else, run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (one step each, child "
+                         "processes) so that roofline.traffic is measured in this run; off / failure: the committed profiles/pmc_traffic.json")
     ap.add_argument("--whole-rows", action="store_true", help="do not split interior / boundary rows")
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
@@ -176,8 +179,14 @@ def stream_copy_GBs(device, nbytes=4 << 30, reps=5):
     return 2.0 * nbytes * reps / (s.elapsed_time(e) * 1e-3) / 1e9
 
 
+IN_RUN_TRAFFIC = {}                # workload name -> (bytes per launch, source): counter passes made by THIS run (measure_traffic_in_run)
+
+
 def pmc_traffic(name):
-    """Fabric (L2-miss) bytes per launch of this workload from the committed rocprofv3 PMC passes, or None."""
+    """Fabric (L2-miss) bytes per launch of this workload: from the rocprofv3 --pmc passes this very run made before its timed
+    region when there are any (measure_traffic_in_run), else from the committed builder-run passes (profiles/pmc_traffic.json), else None."""
+    if name in IN_RUN_TRAFFIC:
+        return IN_RUN_TRAFFIC[name]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None, None
@@ -185,6 +194,85 @@ def pmc_traffic(name):
     if not rec:
         return None, None
     return float(rec["fabric_bytes_per_launch"]), f"profiles/pmc_traffic.json [{rec.get('source', '')}] -- builder-run rocprofv3 --pmc passes of this command, NOT measured in this run"
+
+
+def fabric_bytes_per_launch(fetch_csv, write_csv):
+    """Bytes leaving the L2s per propagation launch from the counter_collection CSVs of a FETCH_SIZE and a WRITE_SIZE pass of one
+    bench command (what profiles/summarize.py computes for the committed files): both counters are in KiB; on gfx950 FETCH_SIZE
+    counts the 128-byte requests of wide coalesced reads as 64 bytes, so the read side is doubled (MI355X_MICROARCH.md, "HBM");
+    one launch = one dispatch of every SpMM kernel, the row kernel of a very large graph being dealt in pieces."""
+    import collections
+    import csv
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in (fetch_csv, write_csv):
+        for r in csv.DictReader(open(path)):
+            if "k_spmm" in r["Kernel_Name"]:
+                per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counts = [len(c["FETCH_SIZE"]) for c in per.values() if c["FETCH_SIZE"]]
+    if not counts:
+        return None
+    launches = min(counts)
+    total = 0.0
+    for c in per.values():
+        fetch = sum(c["FETCH_SIZE"]) / launches
+        write = sum(c["WRITE_SIZE"]) * (len(c["FETCH_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)) / launches if c["WRITE_SIZE"] else 0.0
+        total += 2 * fetch * 1024 + write * 1024
+    return total
+
+
+def measure_traffic_in_run(workloads, seconds=200.0):
+    """rocprofv3 --pmc passes of THIS bench command, made by this process before it touches the GPU (child processes: the program
+    after `--` is the interpreter itself): FETCH_SIZE and WRITE_SIZE, one pass each, per workload -- one propagation step of the
+    same timed call on the same box.  Fills IN_RUN_TRAFFIC, so that roofline.traffic is measured in the driver's own run rather
+    than read from committed files; whatever fails (no rocprofv3, no counter access, time) leaves the committed entry in charge and
+    says so in the returned notes."""
+    import glob
+    import shutil
+    import tempfile
+    notes = {}
+    if shutil.which("rocprofv3") is None:
+        return {w: "rocprofv3 not on PATH" for w in workloads}
+    t_start = time.time()
+    for w in workloads:
+        n, e, C = WORKLOADS[w]
+        name = workload_name(n, e, C)
+        tmp = tempfile.mkdtemp(prefix="gnx_pmc_", dir="/tmp")
+        csvs, problem = {}, None
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            if time.time() - t_start > seconds:
+                problem = "time budget spent"
+                break
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", "python3", os.path.abspath(__file__),
+                   "--workload", w, "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-secondary", "--pmc-in-run", "off"]
+            try:
+                res = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                     text=True, timeout=max(30.0, seconds - (time.time() - t_start)))
+            except Exception as error:
+                problem = repr(error)[:200]
+                break
+            found = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
+            if res.returncode != 0 or not found:
+                problem = f"pass {ctr} failed (rc {res.returncode}): " + (res.stderr or "")[-200:]
+                break
+            csvs[ctr] = max(found, key=os.path.getmtime)
+        if problem is None:
+            try:
+                total = fabric_bytes_per_launch(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"])
+            except Exception as error:
+                total, problem = None, repr(error)[:200]
+            if total:
+                IN_RUN_TRAFFIC[name] = (total, "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py --workload " + w +
+                                        " --steps 1 --warmup 0 --cpu-seconds 0 --no-secondary`, run by THIS bench process on this box before its timed "
+                                        "region (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, per launch)")
+                notes[w] = "measured in this run"
+            elif problem is None:
+                problem = "no SpMM dispatch in the counter files"
+        if problem is not None:
+            notes[w] = "not measured in this run (" + problem + "): the committed entry of profiles/pmc_traffic.json is used"
+        shutil.rmtree(tmp, ignore_errors=True)
+    notes["seconds"] = round(time.time() - t_start, 1)
+    return notes
 
 
 MEASURED_READ_PEAK = [None]        # in-run read-only streaming rate (set once by main)
@@ -555,12 +643,31 @@ def relaunch_under_torchrun(args):
 
 def note(msg):
     """Progress line on stderr (rank 0 only; stdout carries nothing but the JSON line)."""
+    LAST_NOTE[0] = str(msg)
     if int(os.environ.get("RANK", "0")) == 0:
         sys.stderr.write("[bench %7.1fs] %s\n" % (time.time() - T_START, msg))
         sys.stderr.flush()
 
 
 T_START = time.time()
+LAST_NOTE = ["start"]
+
+
+def start_heartbeat(every=60.0):
+    """Rank 0 says it is alive once a minute (stderr): a long silent phase -- plan building at full size, a host-staged rehearsal
+    step -- is otherwise indistinguishable from a hang for whoever watches the run."""
+    import threading
+    if int(os.environ.get("RANK", "0")) != 0:
+        return
+
+    def beat():
+        while True:
+            time.sleep(every)
+            sys.stderr.write("[bench %7.1fs] ... still running (last: %s)\n" % (time.time() - T_START, LAST_NOTE[0][:120]))
+            sys.stderr.flush()
+    threading.Thread(target=beat, daemon=True).start()
+
+
 PHASES = {}                        # seconds per phase of the run (rank 0's clock), printed in config.phases
 
 
@@ -573,6 +680,18 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         relaunch_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    start_heartbeat()
+    pmc_notes = None
+    if world == 1 and args.gpus == 1 and args.pmc_in_run == "on" and not args.force_sharded and args.workload in WORKLOADS \
+            and os.environ.get("GNX_BENCH_PMC", "1") != "0" and not any(k.startswith("ROCPROF") for k in os.environ) \
+            and "rocprof" not in os.environ.get("LD_PRELOAD", ""):          # (never from inside a profiler run)
+        # (nothing in this process has touched the GPU yet: the passes are child processes that come and go before it does)
+        wanted = [args.workload] + (["config4"] if args.workload != "config4" and not args.no_secondary else [])
+        note("counter passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one step each): " + ", ".join(wanted))
+        t_ph = time.time()
+        pmc_notes = measure_traffic_in_run(wanted)
+        phase("pmc_passes_in_run", t_ph)
+        note(f"counter passes: {pmc_notes}")
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
                          f"(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
@@ -639,7 +758,11 @@ def main():
         C_local = C
     else:
         from gnntf import rmat, sharded
-        idx, vals, bounds, comm, (gv, gf, pv, pf), t_gen = rmat.rmat_block_entries(args.nodes, args.entries, seed=1, device=device, grid=(pv, pf))
+        # (gloo rehearsals: an 8 GB broadcast staged through the host is the slow part there; every rank generates the same list instead)
+        note(f"generating the graph ({args.nodes} vertices, {args.entries} entries) and handing every rank its block")
+        idx, vals, bounds, comm, (gv, gf, pv, pf), t_gen = rmat.rmat_block_entries(args.nodes, args.entries, seed=1, device=device, grid=(pv, pf),
+                                                                                   replicate=backend == "gloo" and world > 1)
+        note(f"entries of this rank's block: {idx.shape[0]} ({t_gen:.1f} s)")
         PHASES["startup_and_process_group"] = round(time.time() - T_START - t_gen, 2)
         PHASES["generate_and_broadcast"] = round(t_gen, 2)
         C_local = C // pf                                                       # this rank's feature slice
@@ -893,7 +1016,7 @@ def main():
                        "partition": (f"{pv}_vertex_blocks_x_{pf}_feature_slices" if sharded_path else "none"),
                        "halo": halo, "prep": prep, "kernel": (kernel_blocks if sharded_path else g.last_kernel()),
                        "api": (None if sharded_path else api),
-                       "alt_grid_feature_slices": alt, "self_check": self_check, "phases_s": PHASES},
+                       "alt_grid_feature_slices": alt, "self_check": self_check, "phases_s": PHASES, "pmc_in_run": pmc_notes},
             "roofline": roof,
         }
         if not sharded_path and args.cpu_seconds > 0:

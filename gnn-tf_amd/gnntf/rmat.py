@@ -53,10 +53,13 @@ def rmat_relabelled_pairs(n, m_undirected, seed, device, perm_seed=3):
     return u, v
 
 
-def rmat_block_entries(n_global, entries_global, seed, device, group=None, grid=None):
+def rmat_block_entries(n_global, entries_global, seed, device, group=None, grid=None, replicate=False):
     """This rank's entries of the STRONG-scaling workload: ONE global R-MAT graph (n_global vertices, entries_global stored
     entries -- the same graph for every world size, and the graph bench.py's one-GPU run builds) cut into pv contiguous vertex
     blocks.  Rank 0 generates the edge list and broadcasts it; every rank keeps the entries of its rows.
+    ``replicate``: every rank generates the list itself instead (same seed, same device type: the same list) -- for rehearsals on
+    transports where an 8 GB broadcast is the slow part (gloo, staged through the host); the ranks then compare a checksum of
+    their lists and fail loudly if they differ.
     Returns (idx int64 [m, 2] global (row, col), vals, bounds, comm of the vertex partition, (v, f, pv, pf), seconds)."""
     world_comm = Comm(group=group) if dist.is_initialized() else Comm(solo=True)
     rank, world = world_comm.rank, world_comm.size
@@ -64,13 +67,27 @@ def rmat_block_entries(n_global, entries_global, seed, device, group=None, grid=
     v, f, comm = make_grid(world, rank, pv, pf)
     t0 = time.time()
     m = entries_global // 2
-    if rank == 0:
-        u, w = rmat_relabelled_pairs(n_global, m, seed, device)
-        pairs = torch.stack([u, w])
-        del u, w
+    if replicate and world > 1:
+        for turn in range(world):                          # one rank at a time: the ranks of a rehearsal may share one card
+            if turn == rank:
+                u, w = rmat_relabelled_pairs(n_global, m, seed, device)
+                pairs = torch.stack([u, w])
+                del u, w
+            world_comm.barrier()
+        mark = (pairs[0] * 31 + pairs[1]).sum().reshape(1).to(torch.float64)       # (wraps; equal lists give equal sums)
+        lo_mark, hi_mark = mark.clone(), mark.clone()
+        world_comm.all_reduce(lo_mark, dist.ReduceOp.MIN)
+        world_comm.all_reduce(hi_mark, dist.ReduceOp.MAX)
+        if float(lo_mark) != float(hi_mark):
+            raise Exception("rmat_block_entries: the ranks generated different edge lists")
     else:
-        pairs = torch.empty((2, m), dtype=torch.int64, device=device)
-    world_comm.broadcast(pairs, 0)
+        if rank == 0:
+            u, w = rmat_relabelled_pairs(n_global, m, seed, device)
+            pairs = torch.stack([u, w])
+            del u, w
+        else:
+            pairs = torch.empty((2, m), dtype=torch.int64, device=device)
+        world_comm.broadcast(pairs, 0)
     u, w = pairs[0], pairs[1]
     bounds = uniform_bounds(n_global, pv)
     lo, hi = bounds[v], bounds[v + 1]

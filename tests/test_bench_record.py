@@ -68,3 +68,35 @@ def test_committed_pmc_entries_are_readable():
     traffic, source = bench.pmc_traffic(name)
     assert traffic == table[name]["fabric_bytes_per_launch"] and "NOT measured in this run" in source
     assert bench.pmc_traffic("no_such_workload") == (None, None)
+
+
+def test_fabric_bytes_from_counter_files(tmp_path):
+    """bench.py's own reading of a FETCH_SIZE and a WRITE_SIZE pass (the passes it runs itself before the timed region): KiB,
+    reads doubled, per launch = per dispatch of every SpMM kernel, a row kernel dealt in two pieces counted once per launch;
+    kernels of other names (yardsticks, torch) ignored."""
+    head = "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+
+    def rows(counter, values):
+        out, d = head, 0
+        for kernel, per_dispatch in values:
+            for v in per_dispatch:
+                d += 1
+                out += f'{d},"{kernel}",{counter},{v}\n'
+        return out
+    fetch = rows("FETCH_SIZE", [("void k_spmm_group<4, 32, 4, false>(SpmmArgs)", [100.0, 100.0] * 3),      # two pieces per launch, 3 launches
+                                ("void k_spmm_long_partial_group<4, 32, 4>(SpmmArgs)", [50.0] * 3),
+                                ("void k_spmm_long_reduce<4>(SpmmArgs)", [1.0] * 3), ("k_stream<16, false>", [999.0] * 5)])
+    write = rows("WRITE_SIZE", [("void k_spmm_group<4, 32, 4, false>(SpmmArgs)", [10.0, 10.0] * 3),
+                                ("void k_spmm_long_partial_group<4, 32, 4>(SpmmArgs)", [5.0] * 3),
+                                ("void k_spmm_long_reduce<4>(SpmmArgs)", [2.0] * 3), ("at::native::fill", [7.0])])
+    (tmp_path / "f.csv").write_text(fetch)
+    (tmp_path / "w.csv").write_text(write)
+    total = bench.fabric_bytes_per_launch(str(tmp_path / "f.csv"), str(tmp_path / "w.csv"))
+    assert total == pytest.approx(2 * (200 + 50 + 1) * 1024 + (20 + 5 + 2) * 1024)
+    (tmp_path / "none.csv").write_text(head + '1,"k_stream",FETCH_SIZE,5\n')
+    assert bench.fabric_bytes_per_launch(str(tmp_path / "none.csv"), str(tmp_path / "none.csv")) is None
+
+
+def test_in_run_entries_take_precedence(monkeypatch):
+    monkeypatch.setitem(bench.IN_RUN_TRAFFIC, "rmat_n80000000_nnz1000000000_C128", (1.0e9, "this run"))
+    assert bench.pmc_traffic("rmat_n80000000_nnz1000000000_C128") == (1.0e9, "this run")

@@ -5,7 +5,7 @@ TAG=${1:-r2}; shift
 export TMPDIR=/tmp
 OUT=gpurun_out/${TAG}
 mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --no-secondary $@"
+ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --no-secondary --pmc-in-run off $@"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 bench.py $ARGS > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 echo "stats done"; tail -c 400 $OUT/bench_under_rocprof.json
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err || exit 1
