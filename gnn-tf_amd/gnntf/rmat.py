@@ -100,9 +100,10 @@ def rmat_block_entries(n_global, entries_global, seed, device, group=None, grid=
     return idx, vals, bounds, comm, (v, f, pv, pf), time.time() - t0
 
 
-def build_rmat_blocks(n_global, entries_global, seed, device, backend=None, group=None, grid=None, **graph_options):
+def build_rmat_blocks(n_global, entries_global, seed, device, backend=None, group=None, grid=None, replicate=False, **graph_options):
     """rmat_block_entries + the ShardedGraph over them.  Returns (ShardedGraph, info, (v, f, pv, pf))."""
-    idx, vals, bounds, comm, where, t_gen = rmat_block_entries(n_global, entries_global, seed, device, group=group, grid=grid)
+    idx, vals, bounds, comm, where, t_gen = rmat_block_entries(n_global, entries_global, seed, device, group=group, grid=grid,
+                                                               replicate=replicate)
     t0 = time.time()
     sg = ShardedGraph(idx, vals, bounds, backend=backend, comm=comm, **graph_options)
     del idx, vals

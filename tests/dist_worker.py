@@ -476,8 +476,9 @@ def main():
     else:
         if mode.startswith("grid"):
             pv, pf = (int(x) for x in mode[4:].split("x"))
-        if mode == "blocks":                                       # the bench's strong-scaling generator (one global graph)
-            sg, _, (v, f, pv, pf) = sharded.build_rmat_blocks(1500, 16000, seed=1, device=dev, backend=backend, **options)
+        if mode.startswith("blocks"):                              # the bench's strong-scaling generator (one global graph)
+            sg, _, (v, f, pv, pf) = sharded.build_rmat_blocks(1500, 16000, seed=1, device=dev, backend=backend,
+                                                              replicate=mode == "blocks_replicated", **options)
         else:                                                      # the weak-scaling generator on a pv x pf grid
             sg, _, (v, f, pv, pf) = sharded.build_rmat_shard(500, 6000, seed=1, device=dev, backend=backend, grid=(pv, pf), **options)
         n, lo, hi = sg.n_global, sg.lo, sg.hi
@@ -507,7 +508,7 @@ def main():
         assert sg.stats["push_rows"] == 0 and sg.stats["pull_rows"] == sg.stats["pull_only_rows"]
     if pv == 1:
         assert sum(sg.recv_counts) == 0                            # feature slices alone: no halo, no exchange
-        if mode != "blocks":
+        if not mode.startswith("blocks"):
             assert sg.row_order is not None                        # ... and the weak generator stores the shard degree-relabelled
     plans = [None] * world
     dist.all_gather_object(plans, (v, f, sg.send_counts, sg.recv_counts))
@@ -536,7 +537,7 @@ def main():
         key = g_rows * n + g_cols
         assert len(np.unique(key)) == len(key) and set(key.tolist()) == set((g_cols * n + g_rows).tolist())   # symmetric, no dups
         assert (g_rows != g_cols).all()
-        if mode == "blocks":
+        if mode.startswith("blocks"):
             assert len(key) == 16000                               # exactly the requested number of stored entries
     ai, av = orc.get_adjacency(raw_coo, raw_vals, (n, n))
     _, _, want_vals = orc.coo_to_csr_coalesced(ai, av, (n, n))

@@ -46,6 +46,12 @@ def test_strong_scaling_generator(world):
     launch(world, "blocks")
 
 
+def test_strong_scaling_generator_replicated():
+    """The same workload with every rank generating the edge list itself (what bench.py's gloo rehearsals do instead of an 8 GB
+    host-staged broadcast): the ranks compare checksums of their lists, and the blocks are the blocks of the broadcast form."""
+    launch(3, "blocks_replicated")
+
+
 def test_distributed_generator_world2():
     launch(2, "rmat")
 
