@@ -513,16 +513,18 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     adj1 = sp.dropped_adjacency(g, 0.5, 1, 1, D=scales[1])
     Xd = H0.detach()
     with torch.no_grad():
-        ms_f = median_ms(lambda: sp._launch_chained(adj1, Xd, Xd, 1.0 - a, a, True, scales[2]), reps=5, warm=2)
+        ms_f = median_ms(lambda: sp._launch_chained(adj1, Xd, Xd, 1.0 - a, a, True, scales[2], skip_empty=True), reps=5, warm=2)
         kernel_f = g.last_kernel()
         S_run, Y_run = torch.zeros_like(gout), torch.empty_like(gout)
-        ms_b = median_ms(lambda: sp._launch_back(adj1, gout, True, scales[0], S_run, 1.0, a * (1.0 - a), S_run, 1.0 - a, Y_run), reps=5, warm=2)
+        ms_b = median_ms(lambda: sp._launch_back(adj1, gout, True, scales[0], S_run, 1.0, a * (1.0 - a), S_run, 1.0 - a, Y_run, skip_empty=True),
+                         reps=5, warm=2)
         del S_run, Y_run
         ms_d = median_ms(lambda: sp.dropped_degree_scales(g, 0.5, 1, 0, K), reps=3, warm=1)
     wl = workload_name(n4, e4, C)
     roof_f = roofline_record(n, nnz, C, ms_f * 1e-3, K, "train_forward_" + wl, measured_peak,
                              b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C), what="one forward TRAINING iteration (gnx_spmm_dropped_chained, "
-                             "k >= 1: weights from the counter RNG inside the SpMM, only kept entries gathered) incl. its long-row kernels")
+                             "a middle one: weights from the counter RNG inside the SpMM, only kept entries gathered, rows without entries left to the last "
+                             "iteration) incl. its long-row kernels")
     roof_b = roofline_record(n, nnz, C, ms_b * 1e-3, K, "train_backward_" + wl, measured_peak,
                              b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True), what="one backward TRAINING iteration "
                              "(gnx_spmm_dropped_back over the transposed structure: the running gradient sum updated and the next step's "

@@ -133,6 +133,23 @@ __global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows,
     ids[r] = (int32_t)r;
 }
 
+__global__ void k_count_nonempty(const int64_t *__restrict__ rowptr, int64_t n_rows, unsigned long long *__restrict__ count) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool has = r < n_rows && rowptr[r + 1] > rowptr[r];
+    const unsigned long long votes = __popcll(__ballot(has));
+    if ((threadIdx.x & 63) == 0 && votes) atomicAdd(count, votes);
+}
+
+__global__ void k_mark_referenced(const int32_t *__restrict__ colidx, int64_t nnz, uint8_t *__restrict__ flag) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) flag[colidx[k]] = 1;
+}
+
+__global__ void k_count_empty_referenced(const int64_t *__restrict__ rowptr, int64_t n, const uint8_t *__restrict__ flag, int *__restrict__ count) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && rowptr[r + 1] == rowptr[r] && flag[r]) atomicAdd(count, 1);
+}
+
 __global__ void k_fill_long(const int64_t *__restrict__ rowptr, int64_t n_rows, int long_row, int long_chunk,
                             const int32_t *__restrict__ pos,
                             const int64_t *__restrict__ cpos, int32_t *__restrict__ long_rows,
@@ -225,6 +242,7 @@ void free_csr(Csr &m) {
     if (m.chunk_long) (void)hipFree(m.chunk_long);
     if (m.chunk_order) (void)hipFree(m.chunk_order);
     if (m.row_order) (void)hipFree(m.row_order);
+    if (m.nonempty_rows) (void)hipFree(m.nonempty_rows);
     m = Csr();
 }
 
@@ -249,6 +267,40 @@ int build_long_plan(Csr &m, hipStream_t s) {
         GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint16_t>(), k1.as<uint16_t>(), ids.as<int32_t>(), m.row_order,
                                           (size_t)m.n_rows, 0u, key_bits, s));
         GNX_HIP(hipStreamSynchronize(s));
+    }
+    {   // rows with entries: they lead the order (heaviest first), the empty ones trail it
+        DevBuf count;
+        GNX_HIP(count.alloc(sizeof(unsigned long long)));
+        GNX_HIP(hipMemsetAsync(count.p, 0, sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_count_nonempty, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, count.as<unsigned long long>());
+        unsigned long long host = 0;
+        GNX_HIP(hipMemcpyAsync(&host, count.p, sizeof(host), hipMemcpyDeviceToHost, s));
+        GNX_HIP(hipStreamSynchronize(s));
+        m.n_nonempty = (int64_t)host;
+    }
+    m.empty_rows_unreferenced = false;
+    if (m.n_nonempty < m.n_rows) {
+        if (m.n_nonempty > 0) {   // the rows with entries in ascending order: the leading slots of row_order, sorted by id
+            DevBuf t;
+            GNX_HIP(hipMalloc((void **)&m.nonempty_rows, m.n_nonempty * sizeof(int32_t)));
+            size_t tb = 0;
+            GNX_HIP(rocprim::radix_sort_keys(nullptr, tb, m.row_order, m.nonempty_rows, (size_t)m.n_nonempty, 0u, bits_for((uint64_t)m.n_rows), s));
+            GNX_HIP(t.alloc(tb));
+            GNX_HIP(rocprim::radix_sort_keys(t.p, tb, m.row_order, m.nonempty_rows, (size_t)m.n_nonempty, 0u, bits_for((uint64_t)m.n_rows), s));
+            GNX_HIP(hipStreamSynchronize(s));
+        }
+        if (m.n_rows == m.n_cols) {   // does any entry point at a row that has no entries itself?
+            DevBuf flag, count;
+            GNX_HIP(flag.alloc(m.n_rows)); GNX_HIP(count.alloc(sizeof(int)));
+            GNX_HIP(hipMemsetAsync(flag.p, 0, m.n_rows, s));
+            GNX_HIP(hipMemsetAsync(count.p, 0, sizeof(int), s));
+            if (m.nnz > 0) hipLaunchKernelGGL(k_mark_referenced, dim3(blocks_for(m.nnz)), dim3(256), 0, s, m.colidx, m.nnz, flag.as<uint8_t>());
+            hipLaunchKernelGGL(k_count_empty_referenced, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, flag.as<uint8_t>(), count.as<int>());
+            int host_count = 1;
+            GNX_HIP(hipMemcpyAsync(&host_count, count.p, sizeof(int), hipMemcpyDeviceToHost, s));
+            GNX_HIP(hipStreamSynchronize(s));
+            m.empty_rows_unreferenced = host_count == 0;
+        }
     }
     if (m.nnz == 0) return GNX_OK;
     DevBuf flag, cnt, pos, cpos, tmp;

@@ -69,6 +69,12 @@ struct Csr {
     // rows in stable order of descending (clamped) entry count: the rows that share a wave in the
     // sub-wave kernels then have similar lengths (power-law graphs otherwise leave most lanes idle)
     int32_t *row_order = nullptr;       // [n_rows]
+    int64_t n_nonempty = 0;             // rows with at least one entry: the first n_nonempty slots of row_order (the rest are the empty rows)
+    int32_t *nonempty_rows = nullptr;   // [n_nonempty] the same rows in ASCENDING order (only when some row is empty): what the one-wave-per-row
+                                        // kernels walk while rows without entries are skipped
+    // square structures: no row WITHOUT entries is referenced as a column by any entry (always so for a symmetric pattern).  Such rows
+    // are alpha * H0 after every iteration and nobody gathers them: loops write them into their result only, never into work buffers
+    bool empty_rows_unreferenced = false;
 };
 
 }  // namespace gnx
@@ -186,6 +192,7 @@ struct SpmmArgs {
     float beta2;
     const float *out2_scale;
     int64_t n_rows;
+    int64_t n_nonempty;        // rows with entries = leading slots of row_order (Csr::n_nonempty)
     int64_t slot0;             // first row slot of this launch (a launch holds at most 2^32 work-items: huge graphs are dealt in pieces)
     int C;
     // long rows
@@ -194,6 +201,8 @@ struct SpmmArgs {
     const int32_t *chunk_long;
     const int32_t *chunk_order;
     const int32_t *row_order;
+    const int32_t *nonempty_rows;   // Csr::nonempty_rows (or null)
+    const int32_t *row_list;        // set by the launcher: the wave-per-row kernels take row = row_list[slot] (null: row = slot)
     float *partial;
     int64_t n_long, n_chunks;
     int long_row, long_chunk;

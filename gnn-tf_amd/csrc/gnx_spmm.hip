@@ -212,7 +212,8 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t slot = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
     if (slot >= p.n_rows) return;
-    const int64_t row = (p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot;
+    const int64_t row = p.row_list ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_list[slot])
+                                   : ((p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot);
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > p.long_row) return;  // k_spmm_long_* take it
     if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY: the row already holds alpha * H0 from an earlier iteration
@@ -876,10 +877,12 @@ template <int VEC, int U, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_spmm_wave_drop(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t row = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
-    if (row >= p.n_rows) return;
+    const int64_t slot = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
+    if (slot >= p.n_rows) return;
+    const int64_t row = p.row_list ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_list[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > p.long_row) return;
+    if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY (chained training loops: nobody gathers this row, a later launch writes it)
     for (int c0 = 0; c0 < p.C; c0 += 64 * VEC) {
         const int c = c0 + lane * VEC;
         const bool active = c < p.C;
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
     if (end - beg > p.long_row) return;
+    if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
         const int c = c0 + sub * VEC;
         const bool active = c < p.C;
@@ -1170,8 +1174,24 @@ int pick_vec(const SpmmArgs &p) {
     } while (0)
 
 template <int VEC>
-const char *launch_rows(const SpmmArgs &p, hipStream_t s) {
+const char *launch_rows(const SpmmArgs &p0, hipStream_t s) {
+    SpmmArgs p = p0;
     const int lanes = (p.C + VEC - 1) / VEC;  // lanes needed to cover one row
+    // GNX_ACT_SKIP_EMPTY on the sub-wave kernels: they walk the rows through row_order, whose trailing slots are exactly the rows
+    // without entries -- those slots are not launched at all (on the R-MAT workloads 60 % of the rows: no wave, no row-pointer read)
+    bool trim = lanes <= 32 && p.skip_empty && p.row_order != nullptr && p.n_nonempty < p.n_rows;
+#ifdef GNX_TUNING
+    if (p.tune & (1 << 21)) trim = false;                       // (A/B switch of the tuning build)
+#endif
+    if (trim) p.n_rows = p.n_nonempty;
+    // the one-wave-per-row kernels keep the rows in ascending order (their H0 / out rows stream): they walk the ascending list of
+    // the rows that have entries instead
+    bool list = lanes > 32 && p.skip_empty && p.nonempty_rows != nullptr && p.n_nonempty < p.n_rows && !(p.tune & 1);
+#ifdef GNX_TUNING
+    if (p.tune & (1 << 21)) list = false;
+#endif
+    if (list) { p.row_list = p.nonempty_rows; p.n_rows = p.n_nonempty; }
+    if (p.n_rows == 0) return "spmm_none";
     if (lanes > 32) {
         // measured: U = 8 rows in flight is the plateau (U=4 +0.7 %, U=16 +17 %, forcing 8 waves/SIMD +14 %,
         // degree-ordered rows +9 %, non-temporal H0/out/index loads +-0 %)
@@ -1235,8 +1255,14 @@ void launch_long(const SpmmArgs &p, hipStream_t s) {
 constexpr int DROP_LONG_U = 4;
 
 template <int VEC>
-const char *launch_rows_drop(const SpmmArgs &p, hipStream_t s) {
+const char *launch_rows_drop(const SpmmArgs &p0, hipStream_t s) {
+    SpmmArgs p = p0;
     const int lanes = (p.C + VEC - 1) / VEC;
+    if (p.skip_empty && p.n_nonempty < p.n_rows) {            // as launch_rows: the slots of the rows without entries are not launched
+        if (lanes <= 32 && p.row_order != nullptr) p.n_rows = p.n_nonempty;
+        else if (lanes > 32 && p.nonempty_rows != nullptr) { p.row_list = p.nonempty_rows; p.n_rows = p.n_nonempty; }
+    }
+    if (p.n_rows == 0) return "spmm_none_drop";
     if (lanes > 32) {
         if (p.C <= 64 * VEC) GNX_ROW_PIECES((k_spmm_wave_drop<VEC, 8, 8>), 8, 512);
         else                 GNX_ROW_PIECES((k_spmm_wave_drop<VEC, 8, 4>), 4, 256);
@@ -1302,7 +1328,7 @@ int tune_override = -1;   // set through gnx_debug_set_tune (tuning builds only:
 #endif
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
-    p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows;
+    p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.n_nonempty = m.n_nonempty; p.nonempty_rows = m.nonempty_rows; p.row_list = nullptr;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
     p.chunk_order = m.chunk_order;
@@ -1446,7 +1472,8 @@ int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, u
                              float alpha, int act, float *d_out, int64_t ldo, void *stream) {
     int rc = check_common("gnx_spmm_dropped_chained", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
     if (rc != GNX_OK) return rc;
-    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_spmm_dropped_chained: invalid activation %d", act);
+    GNX_CHECK_ARG((act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_NONE || (act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_RELU, "gnx_spmm_dropped_chained: invalid activation %d", act);
+    if (!g->a.empty_rows_unreferenced) act &= ~GNX_ACT_SKIP_EMPTY;       // honoured only when nobody gathers the rows it would leave untouched
     GNX_CHECK_ARG(d_D != nullptr, "gnx_spmm_dropped_chained: NULL degree scales");
     GNX_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout rate %g outside [0, 1)", (double)dropout_p);
     GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols || g->blk_col_gid != nullptr, "gnx_spmm_dropped_chained: needs a square graph or a vertex block");
@@ -1471,8 +1498,11 @@ int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, u
 int gnx_spmm_dropped_back(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int x_prescaled,
                           const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_S_in, int64_t lds_in,
                           float s_alpha, float s_beta, float *d_S_out, int64_t lds_out, float y_beta, float *d_Y_out, int64_t ldy,
-                          void *stream) {
+                          int act, void *stream) {
     int rc = check_common("gnx_spmm_dropped_back", g, d_X, ldx, C, d_S_in, lds_in, d_S_out, lds_out);
+    if (rc != GNX_OK) return rc;
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_SKIP_EMPTY, "gnx_spmm_dropped_back: act must be GNX_ACT_NONE or GNX_ACT_SKIP_EMPTY");
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || (const void *)d_S_in == (const void *)d_S_out, "gnx_spmm_dropped_back: GNX_ACT_SKIP_EMPTY needs the sum updated in place");
     if (rc != GNX_OK) return rc;
     GNX_CHECK_ARG(d_D != nullptr && d_S_in != nullptr, "gnx_spmm_dropped_back: NULL degree scales / running sum");
     GNX_CHECK_ARG(d_Y_out == nullptr || (ldy >= C && (const void *)d_Y_out != (const void *)d_X && (const void *)d_Y_out != (const void *)d_S_out
@@ -1487,9 +1517,10 @@ int gnx_spmm_dropped_back(gnx_graph_t g, const float *d_D, float dropout_p, uint
     hipStream_t s = (hipStream_t)stream;
     rc = ensure_transpose(g, s);
     if (rc != GNX_OK) return rc;
+    if (!g->t.empty_rows_unreferenced) act = GNX_ACT_NONE;               // honoured only when nobody gathers the rows it would leave untouched
     SpmmArgs p{};
     p.vals = g->t_raw;
-    p.X = d_X; p.ldx = ldx; p.H0 = d_S_in; p.ldh0 = lds_in; p.beta = s_beta; p.alpha = s_alpha; p.act = GNX_ACT_NONE;
+    p.X = d_X; p.ldx = ldx; p.H0 = d_S_in; p.ldh0 = lds_in; p.beta = s_beta; p.alpha = s_alpha; p.act = act;
     p.out = d_S_out; p.ldo = lds_out; p.C = (int)C;
     p.out2 = d_Y_out; p.ldo2 = ldy; p.beta2 = y_beta; p.out2_scale = d_Y_out ? d_D_next : nullptr;
     p.fuse.D = d_D; p.fuse.seed = seed; p.fuse.stream = stream_id; p.fuse.offset = g->stream_offset;
@@ -1558,7 +1589,7 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
         SpmmArgs p{};
         p.vals = d_vals ? d_vals : g->raw_vals;
         p.X = d_H; p.ldx = C; p.H0 = d_H0; p.ldh0 = C; p.beta = beta; p.alpha = a; p.act = act; p.out = d_out; p.ldo = C; p.C = (int)C;
-        p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.row_order = m.row_order;
+        p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.n_nonempty = m.n_nonempty; p.row_order = m.row_order;
         p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
         p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
         static PerDeviceOnce configured;
@@ -1609,7 +1640,7 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
     SpmmArgs p{};
     p.vals = d_vals ? d_vals : g->raw_vals;
     p.X = d_H; p.ldx = C; p.H0 = d_H0; p.ldh0 = C; p.beta = beta; p.alpha = a; p.act = act; p.out = d_out; p.ldo = C; p.C = (int)C;
-    p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.row_order = m.row_order;
+    p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.n_nonempty = m.n_nonempty; p.row_order = m.row_order;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
     p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     const unsigned grid = blocks_for(blocks_for(m.n_rows, 16), 8);
@@ -1651,6 +1682,11 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
     }
     const int64_t n = g->a.n_rows;
     hipStream_t s = (hipStream_t)stream;
+#ifdef GNX_TUNING   // (A/B switch of the tuning build: bit 1 << 20 = treat rows without entries as possibly referenced, the rule before round 4)
+    struct Restore { gnx_graph *g; bool a, r; ~Restore() { g->a.empty_rows_unreferenced = a; g->r.empty_rows_unreferenced = r; } }
+        restore{g, g->a.empty_rows_unreferenced, g->r.empty_rows_unreferenced};
+    if (tune_override >= 0 && (tune_override & (1 << 20))) g->a.empty_rows_unreferenced = g->r.empty_rows_unreferenced = false;
+#endif
     // Narrow features on a large graph: every gather moves a whole 128-byte line for a 16..64-byte row, so what counts is how
     // often a line is found in cache.  The K iterations then run on the degree-relabelled copy of the matrix (hub rows adjacent:
     // four to eight of the rows that receive most gathers share a line): H0 is permuted once on the way in, the LAST iteration
@@ -1671,7 +1707,8 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
             float *dst = last ? d_out : (((K - 2 - k) % 2 == 0) ? d_work : d_out);
             SpmmArgs p{};
             p.vals = g->r_vals; p.X = src; p.ldx = C; p.H0 = g->r_feat; p.ldh0 = C; p.beta = (float)(1.0 - (double)a); p.alpha = a;
-            p.act = (k >= 2 && !last) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
+            // rows without entries: written by the last iteration (it scatters every row); in between only if somebody gathers them
+            p.act = (!last && (k >= 2 || g->r.empty_rows_unreferenced)) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
             p.out = dst; p.ldo = C; p.C = (int)C;
             p.out_rows = last ? g->r_order : nullptr;               // relabelled row i is the caller's row r_order[i]
             rc = launch_spmm(g, g->r, p, s);
@@ -1686,7 +1723,10 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
     const float *src = d_H0;
     for (int k = 0; k < K; ++k) {
         float *dst = ((K - 1 - k) % 2 == 0) ? d_out : d_work;
-        const int act = (k >= 2 && d_diag == nullptr) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
+        // ... and when no entry points at such a row (g->a.empty_rows_unreferenced: every symmetric pattern) nobody ever gathers it: the
+        // work buffer never needs it, the result buffer gets it the first time it is a destination
+        const bool settled = k >= 2 || (g->a.empty_rows_unreferenced && dst == d_work);
+        const int act = (settled && d_diag == nullptr) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
         GNX_CHECK_ARG(d_H0 != nullptr, "gnx_appnp_propagate: NULL H0");
         int rc = gnx_spmm(g, d_vals, d_diag, src, C, C, d_H0, C, (float)(1.0 - (double)a), a, act, dst, C, stream);
         if (rc != GNX_OK) return rc;

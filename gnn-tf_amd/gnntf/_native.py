@@ -50,7 +50,7 @@ SIGNATURES = {
     "gnx_spmm_dropped_chained": (c_int, [c_void_p, c_void_p, c_float, c_uint64, c_uint64, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                                          c_int64, c_float, c_float, c_int, c_void_p, c_int64, c_void_p]),
     "gnx_spmm_dropped_back": (c_int, [c_void_p, c_void_p, c_float, c_uint64, c_uint64, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-                                      c_int64, c_float, c_float, c_void_p, c_int64, c_float, c_void_p, c_int64, c_void_p]),
+                                      c_int64, c_float, c_float, c_void_p, c_int64, c_float, c_void_p, c_int64, c_int, c_void_p]),
     "gnx_spmm_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_int,
                               c_void_p, c_void_p, c_int64, c_void_p]),
     "gnx_spmm_tv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float,

@@ -676,6 +676,7 @@ class ShardedGraph:
         self.pull_counts, self.push_counts = [0], [0]
         self.n_send = self.n_send_pull = 0
         self.send_graph = self.push_graph = self.halo = None
+        self.empty_rows_unreferenced = False
         self.stats = dict(pull_rows=0, push_rows=0, pull_only_rows=0, send_rows=0, interior_rows=self.n_local,
                           boundary_rows=0, local_rows=self.n_local)
 
@@ -778,6 +779,18 @@ class ShardedGraph:
         s_vals = torch.cat(s_vals) if s_vals else torch.zeros(0, dtype=torch.float32, device=dev)
         if s_cols.numel() and (int(s_cols.min()) < 0 or int(s_cols.max()) >= n_local):
             raise Exception("ShardedGraph: a peer asked for a partial sum over rows this rank does not own")
+        # Is any local row WITHOUT entries used by somebody -- as a local column of this block, as a row a peer pulls, or inside a
+        # partial sum pushed to a peer?  If none is (always so for a symmetric pattern: such a vertex is isolated), nobody ever
+        # gathers those rows: propagate() writes them into the result only, never into the ping-pong buffers
+        used = torch.zeros(max(n_local, 1), dtype=torch.bool, device=dev)
+        local_cols = m_cols[(m_cols >= n_before) & (m_cols < n_before + n_local)] - n_before
+        used[local_cols] = True
+        used[pull_src] = True
+        used[s_cols] = True
+        has_entries = torch.zeros(max(n_local, 1), dtype=torch.bool, device=dev)
+        has_entries[m_rows] = True
+        self.empty_rows_unreferenced = not bool((used & ~has_entries)[:n_local].any())
+        del used, has_entries, local_cols
         self.push_graph = be.graph_from_coo(torch.stack([s_rows, s_cols], 1), s_vals, (n_push, n_local)) if n_push else None
         self.halo = be.halo_plan(me, n_local, self.pull_counts, self.push_counts, self.send_pull_counts, self.send_push_counts,
                                  self.send_pull_src, self.push_graph)
@@ -912,7 +925,8 @@ class ShardedGraph:
             last = k == iterations - 1
             # a row without entries is a * H0 after every iteration: it is written the first time each ping-pong buffer is a
             # destination (k = 0, 1) and into the result (last iteration), and left alone in between
-            settled = 2 <= k < iterations - 1
+            # ... and when nobody references such rows at all (self.empty_rows_unreferenced) only the result ever needs them
+            settled = (k >= 2 or self.empty_rows_unreferenced) and k < iterations - 1
             for c, (c0, c1) in enumerate(state.cols):
                 src, dst = state.bufs[c][k % 2], state.bufs[c][1 - k % 2]
                 with lanes.exchange_lane():                            # runs under the other chunk's SpMM

@@ -299,9 +299,10 @@ def _launch(adj: Adjacency, X, H0, beta, alpha, act, transposed=False, out=None,
     return out
 
 
-def _launch_chained(adj: "DroppedAdjacency", X, H0, beta, alpha, prescaled, D_next):
+def _launch_chained(adj: "DroppedAdjacency", X, H0, beta, alpha, prescaled, D_next, skip_empty=False):
     """One forward training iteration inside a loop (gnx_spmm_dropped_chained): X carries its column scale when ``prescaled``,
-    the result carries ``D_next`` (the next iteration's column scale) unless that is None."""
+    the result carries ``D_next`` (the next iteration's column scale) unless that is None.  ``skip_empty``: rows without entries
+    are left untouched (every iteration but the last: nobody gathers them; the library ignores it on graphs where somebody does)."""
     g = adj.graph
     nat.require_cuda(X, H0)
     _same_device(g, X, H0, adj.D, D_next)
@@ -311,12 +312,12 @@ def _launch_chained(adj: "DroppedAdjacency", X, H0, beta, alpha, prescaled, D_ne
     with nat.on_device(X.device):
         nat.check(nat.lib().gnx_spmm_dropped_chained(g.handle, nat.ptr(adj.D), adj.p, adj.seed, adj.stream_id, 1 if prescaled else 0,
                                                      nat.ptr(D_next), nat.ptr(X), X.stride(0), X.shape[1], nat.ptr(H0), H0.stride(0),
-                                                     float(beta), float(alpha), nat.ACT_NONE, nat.ptr(out), out.stride(0),
-                                                     nat.current_stream()))
+                                                     float(beta), float(alpha), nat.ACT_NONE | (nat.ACT_SKIP_EMPTY if skip_empty else 0),
+                                                     nat.ptr(out), out.stride(0), nat.current_stream()))
     return out
 
 
-def _launch_back(adj: "DroppedAdjacency", X, prescaled, D_next, S_in, s_alpha, s_beta, S_out, y_beta, Y_out):
+def _launch_back(adj: "DroppedAdjacency", X, prescaled, D_next, S_in, s_alpha, s_beta, S_out, y_beta, Y_out, skip_empty=False):
     """One backward training iteration inside a loop (gnx_spmm_dropped_back): acc = A_k^T X over the transposed structure, weights
     made in the kernel; S_out = s_beta acc + s_alpha S_in (S_in may be S_out), Y_out = y_beta acc * D_next (skipped when None)."""
     g = adj.graph
@@ -328,7 +329,8 @@ def _launch_back(adj: "DroppedAdjacency", X, prescaled, D_next, S_in, s_alpha, s
     with nat.on_device(X.device):
         nat.check(nat.lib().gnx_spmm_dropped_back(g.handle, nat.ptr(adj.D), adj.p, adj.seed, adj.stream_id, 1 if prescaled else 0, nat.ptr(D_next),
                                                   nat.ptr(X), C, C, nat.ptr(S_in), C, float(s_alpha), float(s_beta), nat.ptr(S_out), C,
-                                                  float(y_beta), nat.ptr(Y_out), C, nat.current_stream()))
+                                                  float(y_beta), nat.ptr(Y_out), C, nat.ACT_SKIP_EMPTY if skip_empty else nat.ACT_NONE,
+                                                  nat.current_stream()))
 
 
 def _backward_chained(adjs, g, a):
@@ -343,8 +345,9 @@ def _backward_chained(adjs, g, a):
     for k in range(K - 1, -1, -1):
         first, last = k == K - 1, k == 0
         Y = None if last else torch.empty_like(g)
+        # rows without entries: their g_k is 0 -- after the first call their sum is final and their Y row is never gathered
         _launch_back(adjs[k], X, not first, None if last else adjs[k - 1].D, g if first else S, a if first else 1.0,
-                     (1.0 - a) if last else a * (1.0 - a), S, 1.0 - a, Y)
+                     (1.0 - a) if last else a * (1.0 - a), S, 1.0 - a, Y, skip_empty=not first)
         X = Y
     return S
 
@@ -455,7 +458,9 @@ class _PPRLoop(torch.autograd.Function):
             ctx.chained = chained and first.graph.n_rows == first.graph.n_cols
             for k, adj in enumerate(adjs):
                 if chained:
-                    H = _launch_chained(adj, H, H0, 1.0 - a, a, prescaled=k > 0, D_next=adjs[k + 1].D if k + 1 < K else None)
+                    # (rows without entries are a * H0 in the result and gathered by nobody: only the last iteration writes them)
+                    H = _launch_chained(adj, H, H0, 1.0 - a, a, prescaled=k > 0, D_next=adjs[k + 1].D if k + 1 < K else None,
+                                        skip_empty=k + 1 < K)
                 else:
                     H = _launch(adj, H, H0, 1.0 - a, a, nat.ACT_NONE)
         else:

@@ -224,11 +224,15 @@ int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, u
  * entry (profiles/NOTES.md round 4: +4.5 GB per launch at config 4, C = 64).  The loop: X = upstream gradient, S_in = X,
  * s_alpha = a for the first call; afterwards X = the previous Y_out, S_in = S_out, s_alpha = 1; s_beta = a (1-a), y_beta = 1-a;
  * the last call (stream 0) adds g_0 whole: s_beta = 1-a, no Y_out.  Square stand-alone graphs without duplicate entries.
+ * act: GNX_ACT_NONE, or GNX_ACT_SKIP_EMPTY (with S_in == S_out) for every call but the first of a loop: rows without entries
+ * contribute g_k = 0, so their sum stays what the first call made it and their Y row is never gathered -- they are left untouched
+ * (honoured only on graphs where no entry references a row without entries; gnx_spmm_dropped_chained takes the same flag for
+ * every iteration but the last of a forward loop).
  * Finite operands only (a dropped entry's row is not gathered), as for gnx_spmm_dropped. */
 int gnx_spmm_dropped_back(gnx_graph_t g, const float *d_D, float dropout_p, uint64_t seed, uint64_t stream_id, int x_prescaled,
                           const float *d_D_next, const float *d_X, int64_t ldx, int64_t C, const float *d_S_in, int64_t lds_in,
                           float s_alpha, float s_beta, float *d_S_out, int64_t lds_out, float y_beta, float *d_Y_out, int64_t ldy,
-                          void *stream);
+                          int act, void *stream);
 
 /* gnx_spmm_rows: the fused step for a handle that holds only a SUBSET of the output rows (the interior or the
  * boundary rows of a vertex block, compacted): result row r lands in out[d_rows[r], :] and mixes in

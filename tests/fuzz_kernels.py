@@ -59,6 +59,28 @@ for case in range(cases):
                 a_ = _launch(fused, dev(X), dev(H0), 0.9, 0.1, 0, transposed=tr)
                 b_ = _launch(two, dev(X), dev(H0), 0.9, 0.1, 0, transposed=tr)
                 assert torch.equal(a_, b_), f"dropped case {case} transposed={tr}: {float((a_ - b_).abs().max())}"
+            # the training loops: column sums of K streams in one call (bitwise the one-stream sums), the chained forward and the
+            # chained backward (running gradient sum + pre-scaled operand in the epilogue) against K un-chained launches
+            K, a_ = int(rng.integers(2, 7)), 0.1
+            D = gnntf.sparse.dropped_degree_scales(g, p, 5, case, K)
+            for k in range(K):
+                assert torch.equal(D[k], gnntf.sparse.dropped_degree_scales(g, p, 5, case + k, 1)[0]), f"scales case {case} stream {k}"
+            adjs = [gnntf.sparse.dropped_adjacency(g, p, 5, case + k, D=D[k]) for k in range(K)]
+            tol = 2e-5 * (1.0 + np.sqrt(longest) / 10.0)
+            rel = lambda x, y: float(((x - y).abs() / y.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)).max())
+            with torch.no_grad():
+                f_got = gnntf.sparse.ppr_loop(lambda k, bwd=False: adjs[k], dev(H0), a_, K)
+                f_want = dev(H0)
+                for k in range(K):
+                    f_want = _launch(adjs[k], f_want, dev(H0), 1.0 - a_, a_, 0)
+            assert rel(f_got, f_want) < tol, f"chained forward case {case}: {rel(f_got, f_want)}"
+            up = dev(X)
+            b_got = gnntf.sparse._backward_chained(adjs, up, a_)
+            gk, b_want = up, up * a_
+            for k in range(K - 1, -1, -1):
+                gk = _launch(adjs[k], gk, None, 1.0 - a_, 0.0, 0, transposed=True)
+                b_want = b_want + gk * (a_ if k >= 1 else 1.0)
+            assert rel(b_got, b_want) < tol, f"chained backward case {case}: {rel(b_got, b_want)}"
             stats["dropped"] += 1
         elif kind == 2 and nnz:
             adj = gnntf.normalize(g, "symmetric")

@@ -222,6 +222,33 @@ def test_k_loop_skips_settled_empty_rows_bitwise(gnntf):
     assert torch.equal(gnntf.appnp_propagate(eye, H0, a=0.2, iterations=5), H)
 
 
+def test_k_loop_never_writes_unreferenced_empty_rows_into_work_buffers(gnntf):
+    """Symmetric patterns: a row without entries is referenced by nobody, so the K loop writes it into the RESULT only (the first time
+    the result buffer is a destination) and never into the work buffer -- same bits as K full steps for every parity of K, and
+    nothing ever reads the rows it left untouched (work and result buffers poisoned with NaN beforehand)."""
+    from gnntf import _native as nat
+    coo, vals, shape = graphs.rmat_symmetric_coo(6000, 9000, seed=5)               # sparse enough to leave isolated vertices
+    n = shape[0]
+    isolated = np.setdiff1d(np.arange(n), coo[:, 0])
+    assert len(isolated) > 100
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, "symmetric")
+    for C in (8, 64, 256):
+        H0 = dev(np.random.default_rng(C).standard_normal((n, C)).astype(np.float32))
+        for K in (1, 2, 3, 6, 7):
+            H = H0
+            for _ in range(K):
+                H = gnntf.ppr_step(adj, H, H0, 0.2)
+            out = torch.full_like(H0, float("nan"))
+            work = torch.full_like(H0, float("nan"))
+            nat.check(nat.lib().gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), 0.2, K, C, nat.ptr(out), nat.ptr(work),
+                                                    nat.current_stream()))
+            assert torch.equal(out, H), (C, K)
+            assert torch.equal(out[isolated], H0[isolated] * 0.2)
+            if K >= 2:                                                        # the work buffer never received them
+                assert bool(torch.isnan(work[isolated]).all()), (C, K)
+
+
 def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
     """gnx_appnp_propagate at C <= 16 on a large graph runs on the degree-relabelled copy of the matrix (H0 permuted in, the last
     iteration scattered back): same result as K plain steps up to float32 rounding (the columns of a row are summed in another
@@ -246,6 +273,23 @@ def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
             else:
                 assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
                 assert torch.equal(got[int(n * 0.75):], H[int(n * 0.75):])           # rows without entries: exactly a * H0
+    del g, adj
+    # the same pattern made symmetric: rows without entries are referenced by nobody, and the loop then writes them by its last
+    # (scattering) iteration only -- never into a work buffer
+    sym = torch.unique(torch.cat([idx, idx.flip(1)]), dim=0)
+    sym = sym[sym[:, 0] < int(n * 0.7)]
+    sym = torch.unique(torch.cat([sym, sym.flip(1)]), dim=0)
+    sym = sym[(sym[:, 0] < int(n * 0.7)) & (sym[:, 1] < int(n * 0.7))]
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(sym, torch.ones(sym.shape[0], device="cuda"), (n, n)), device="cuda:0")
+    adj = gnntf.normalize(g, "symmetric")
+    for C, K in ((8, 1), (8, 2), (16, 5)):
+        H0 = torch.rand(n, C, device="cuda", generator=gen) * 2 - 1
+        H = H0
+        for _ in range(K):
+            H = gnntf.ppr_step(adj, H, H0, 0.15)
+        got = gnntf.appnp_propagate(adj, H0, a=0.15, iterations=K)
+        assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
+        assert torch.equal(got[int(n * 0.75):], H0[int(n * 0.75):] * 0.15)
     del g, adj
 
 

@@ -71,13 +71,13 @@ def main():
     X = H0.detach()
     adj1 = sparse.dropped_adjacency(g, 0.5, 1, 1, D=scales[1])
     with torch.no_grad():
-        sparse._launch_chained(adj1, X, X, 0.9, 0.1, True, scales[2])
+        sparse._launch_chained(adj1, X, X, 0.9, 0.1, True, scales[2], skip_empty=True)
         S_run, Y_run = torch.zeros_like(gout), torch.empty_like(gout)
-        back = lambda: sparse._launch_back(adj1, gout, True, scales[0], S_run, 1.0, 0.09, S_run, 0.9, Y_run)
+        back = lambda: sparse._launch_back(adj1, gout, True, scales[0], S_run, 1.0, 0.09, S_run, 0.9, Y_run, skip_empty=True)
         back()
         torch.cuda.synchronize()
         mark()
-        res["forward_launch_ms"] = timed(lambda: sparse._launch_chained(adj1, X, X, 0.9, 0.1, True, scales[2]), a.launches)
+        res["forward_launch_ms"] = timed(lambda: sparse._launch_chained(adj1, X, X, 0.9, 0.1, True, scales[2], skip_empty=True), a.launches)
         res["kernel"] = g.last_kernel()
         mark()
         res["backward_launch_ms"] = timed(back, a.launches)
