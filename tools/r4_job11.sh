@@ -1,0 +1,26 @@
+#!/bin/bash
+# re-measure after the empty-row changes: profile set, training passes, block passes
+export TMPDIR=/tmp
+if [ "$1" != "skip-profiles" ]; then bash tools/r4_job7.sh || exit 1; fi
+O=gpurun_out/r4c
+mkdir -p $O
+rm -rf $O/train_stats $O/train_fetch $O/train_write
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o run -- python3 tools/train_roofline.py > $O/train_under_stats.json 2> $O/train_stats.err || { echo "train stats failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/train_fetch -o run -- python3 tools/train_roofline.py > $O/train_fetch.json 2> $O/train_fetch.err || { echo "train fetch failed"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/train_write -o run -- python3 tools/train_roofline.py > $O/train_write.json 2> $O/train_write.err || { echo "train write failed"; exit 1; }
+find $O -name "*_kernel_trace.csv" -size +20M -delete
+echo "train passes done"
+O=gpurun_out/r4d
+mkdir -p $O
+for cfg in "8 cover 2" "8 cover 4" "8 pull 2" "4 cover 2" "2 cover 2"; do
+  set -- $cfg; P=$1; COVER=$2; CH=$3
+  T=p${P}_${COVER}_c${CH}
+  rm -rf $O/${T}_FETCH_SIZE $O/${T}_WRITE_SIZE
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $O/${T}_$ctr -o run -- python3 tools/sim_blocks.py --world $P --cover $COVER --chunks $CH --pmc-iterations 5 \
+        > $O/${T}_$ctr.json 2> $O/${T}_$ctr.err || { echo "$T $ctr failed"; tail -5 $O/${T}_$ctr.err; exit 1; }
+  done
+  echo "$T done: $(tail -c 200 $O/${T}_FETCH_SIZE.json)"
+done
+for P in 2 4 8; do timeout -k 10 300 python3 tools/sim_blocks.py --world $P > gpurun_out/r4d/sim_blocks_p$P.json 2> gpurun_out/r4d/sim_blocks_p$P.err || { echo "sim $P failed"; exit 1; }; done
+echo "all done"
