@@ -133,6 +133,15 @@ __global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows,
     ids[r] = (int32_t)r;
 }
 
+__global__ void k_slot_ptrs(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ row_order, int64_t n_rows,
+                            int64_t *__restrict__ slot_beg, int32_t *__restrict__ slot_cnt) {
+    int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_rows) return;
+    const int64_t r = row_order[sidx], b = rowptr[r], e = rowptr[r + 1];
+    slot_beg[sidx] = b;
+    slot_cnt[sidx] = (int32_t)(e - b < 0x7fffffff ? e - b : 0x7fffffff);
+}
+
 __global__ void k_count_nonempty(const int64_t *__restrict__ rowptr, int64_t n_rows, unsigned long long *__restrict__ count) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool has = r < n_rows && rowptr[r + 1] > rowptr[r];
@@ -243,6 +252,8 @@ void free_csr(Csr &m) {
     if (m.chunk_order) (void)hipFree(m.chunk_order);
     if (m.row_order) (void)hipFree(m.row_order);
     if (m.nonempty_rows) (void)hipFree(m.nonempty_rows);
+    if (m.slot_beg) (void)hipFree(m.slot_beg);
+    if (m.slot_cnt) (void)hipFree(m.slot_cnt);
     m = Csr();
 }
 
@@ -267,6 +278,11 @@ int build_long_plan(Csr &m, hipStream_t s) {
         GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint16_t>(), k1.as<uint16_t>(), ids.as<int32_t>(), m.row_order,
                                           (size_t)m.n_rows, 0u, key_bits, s));
         GNX_HIP(hipStreamSynchronize(s));
+    }
+    if (m.n_rows >= SMALL_ROWS) {   // big structures: the rows' entry ranges in slot order
+        GNX_HIP(hipMalloc((void **)&m.slot_beg, m.n_rows * sizeof(int64_t)));
+        GNX_HIP(hipMalloc((void **)&m.slot_cnt, m.n_rows * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_slot_ptrs, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.row_order, m.n_rows, m.slot_beg, m.slot_cnt);
     }
     {   // rows with entries: they lead the order (heaviest first), the empty ones trail it
         DevBuf count;

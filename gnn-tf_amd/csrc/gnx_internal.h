@@ -69,6 +69,9 @@ struct Csr {
     // rows in stable order of descending (clamped) entry count: the rows that share a wave in the
     // sub-wave kernels then have similar lengths (power-law graphs otherwise leave most lanes idle)
     int32_t *row_order = nullptr;       // [n_rows]
+    int64_t *slot_beg = nullptr;        // [n_rows] first entry of row row_order[slot] ...
+    int32_t *slot_cnt = nullptr;        // [n_rows] ... and its entry count: what the sub-wave kernels read instead of rowptr[row_order[slot]]
+                                        // (coalesced, and no load that depends on another load before the row's entries are known)
     int64_t n_nonempty = 0;             // rows with at least one entry: the first n_nonempty slots of row_order (the rest are the empty rows)
     int32_t *nonempty_rows = nullptr;   // [n_nonempty] the same rows in ASCENDING order (only when some row is empty): what the one-wave-per-row
                                         // kernels walk while rows without entries are skipped
@@ -201,6 +204,8 @@ struct SpmmArgs {
     const int32_t *chunk_long;
     const int32_t *chunk_order;
     const int32_t *row_order;
+    const int64_t *slot_beg;        // Csr::slot_beg / slot_cnt (or null)
+    const int32_t *slot_cnt;
     const int32_t *nonempty_rows;   // Csr::nonempty_rows (or null)
     const int32_t *row_list;        // set by the launcher: the wave-per-row kernels take row = row_list[slot] (null: row = slot)
     float *partial;

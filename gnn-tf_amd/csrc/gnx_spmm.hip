@@ -237,7 +237,9 @@ __device__ __forceinline__ void group_rows(const SpmmArgs &p, int64_t block) {
     const int64_t slot = p.slot0 + block * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;   // degree-binned: the rows of one wave have similar lengths
-    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    int64_t beg, end;
+    if (p.slot_beg) { beg = p.slot_beg[slot]; end = beg + p.slot_cnt[slot]; }      // (slot order: coalesced, independent of the row_order load)
+    else { beg = p.rowptr[row]; end = p.rowptr[row + 1]; }
     if (end - beg > p.long_row) return;
     if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
@@ -322,7 +324,9 @@ __device__ __forceinline__ void group_rows_coop(const SpmmArgs &p, int64_t block
     const int64_t slot = p.slot0 + block * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
-    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    int64_t beg, end;
+    if (p.slot_beg) { beg = p.slot_beg[slot]; end = beg + p.slot_cnt[slot]; }
+    else { beg = p.rowptr[row]; end = p.rowptr[row + 1]; }
     if (end - beg > p.long_row) return;
     if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
@@ -903,7 +907,9 @@ __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
     const int64_t slot = p.slot0 + (int64_t)blockIdx.x * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
-    const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
+    int64_t beg, end;
+    if (p.slot_beg) { beg = p.slot_beg[slot]; end = beg + p.slot_cnt[slot]; }
+    else { beg = p.rowptr[row]; end = p.rowptr[row + 1]; }
     if (end - beg > p.long_row) return;
     if (p.skip_empty && beg == end) return;   // GNX_ACT_SKIP_EMPTY
     for (int c0 = 0; c0 < p.C; c0 += G * VEC) {
@@ -1329,6 +1335,7 @@ int tune_override = -1;   // set through gnx_debug_set_tune (tuning builds only:
 
 int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.n_nonempty = m.n_nonempty; p.nonempty_rows = m.nonempty_rows; p.row_list = nullptr;
+    p.slot_beg = m.slot_beg; p.slot_cnt = m.slot_cnt;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
     p.chunk_order = m.chunk_order;
@@ -1339,6 +1346,9 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     }
 #else
     p.tune = 0;
+#endif
+#ifdef GNX_TUNING   // A/B switch of the tuning build: bit 1 << 22 = entry ranges through rowptr[row_order[slot]] as before round 4
+    if (p.tune & (1 << 22)) p.slot_beg = nullptr;
 #endif
     p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     p.partial = nullptr;
