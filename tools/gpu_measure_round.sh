@@ -1,7 +1,10 @@
 #!/bin/bash
-# re-measure after the empty-row changes: profile set, training passes, block passes
+# Everything profiles/ holds for a round, re-measured in one visit: the profile set (tools/gpu_profile_set.sh), the training step's
+# kernel-stats / FETCH_SIZE / WRITE_SIZE passes (tools/train_roofline.py), the counter passes of rank 0's vertex blocks and their
+# rehearsals (tools/sim_blocks.py).  Summaries: profiles/summarize.py, summarize_train.py, summarize_blocks.py.
+#   gpurun --timeout 1200 -- 'bash tools/gpu_measure_round.sh [skip-profiles]'
 export TMPDIR=/tmp
-if [ "$1" != "skip-profiles" ]; then bash tools/r4_job7.sh || exit 1; fi
+if [ "$1" != "skip-profiles" ]; then bash tools/gpu_profile_set.sh || exit 1; fi
 O=gpurun_out/r4c
 mkdir -p $O
 rm -rf $O/train_stats $O/train_fetch $O/train_write

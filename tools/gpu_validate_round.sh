@@ -1,5 +1,7 @@
 #!/bin/bash
-# final validation of the round: -m gpu tests, the default bench line (in-run counter passes), reduced-size rehearsals of N > 1
+# Validation of a round in one visit: the -m gpu tests, the default bench line (with its in-run counter passes), reduced-size all-auto
+# rehearsals of N > 1 on gloo ranks, a seeded kernel fuzz.
+#   gpurun --timeout 1200 -- 'bash tools/gpu_validate_round.sh'
 mkdir -p gpurun_out/r4k
 timeout -k 10 900 python -m pytest tests -m gpu -q -x > gpurun_out/r4k/tests.log 2>&1; rc=$?
 tail -4 gpurun_out/r4k/tests.log; echo "pytest rc=$rc"

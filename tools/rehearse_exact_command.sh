@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU visit 5: the EXACT command the driver runs for N > 1 -- `python3 bench.py --gpus 5`, every option at its default
+# The EXACT command the driver runs for N > 1 -- `python3 bench.py --gpus 5`, every option at its default
 # (config 5 at full size, all-auto variant selection within its wall-clock budget, overlap probe, self check) -- rehearsed with five
 # gloo ranks sharing the one card (GNX_BENCH_BACKEND=gloo: the exchange is staged through the host, so rates mean nothing; what
 # counts is that every phase runs, how long each takes, and that the line is well-formed).
