@@ -40,8 +40,9 @@ enum { GNX_EYE_NONE = 0, GNX_EYE_BEFORE = 1, GNX_EYE_AFTER = 2 };
 /* epilogue activation: identity (filter.py:8 default) or relu (gcn.py:78 default) */
 enum { GNX_ACT_NONE = 0, GNX_ACT_RELU = 1 };
 /* flag OR'ed into `act` of gnx_spmm / gnx_spmm_rows: rows without stored entries are NOT written (their output would be
- * alpha * H0[row], which is what an earlier iteration of a propagation loop already left there) -- they cost one rowptr read
- * instead of a row of H0 and a row of out.  Ignored when a diagonal weight is given. */
+ * alpha * H0[row], which is what an earlier iteration of a propagation loop already left there) -- and cost nothing: the kernels
+ * that walk the rows in degree-binned order do not launch their slots at all, the one-wave-per-row kernels walk the ascending
+ * list of the rows that have entries.  Ignored when a diagonal weight is given. */
 enum { GNX_ACT_SKIP_EMPTY = 256 };
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
@@ -252,7 +253,8 @@ int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const 
  * (square graph).  d_work is a caller-provided scratch [n, C]; the result lands in d_out.
  * d_out, d_work and d_H0 must be distinct buffers.  Two things the loop does that K separate gnx_ppr_step calls do not:
  *   - rows without stored entries (a * H0 after every iteration) are computed when each buffer is first a destination and left
- *     alone afterwards (GNX_ACT_SKIP_EMPTY) -- same bits, fewer bytes;
+ *     alone afterwards (GNX_ACT_SKIP_EMPTY) -- same bits, fewer bytes; when no entry references such a row (every symmetric
+ *     pattern) they are written into d_out only and d_work never receives them (its rows of that kind stay as the caller left them);
  *   - for C <= 16 on graphs of at least 2^20 vertices (no diagonal) the iterations run on a degree-relabelled copy of the
  *     matrix (heaviest vertices first; inside a degree bin the vertices follow their most popular neighbour's rank) that the
  *     handle builds on first use (+ about 12 bytes per entry and an [n, C] scratch, owned by the handle): H0 is
