@@ -179,11 +179,15 @@ __global__ __launch_bounds__(256) void k_keep_masks(const int32_t *__restrict__ 
     mask[p] = (uint16_t)bits;
 }
 
+// ``list`` / ``n_slots``: the columns WITH entries in ascending order (the transposed structure's nonempty_rows; the sums of the others
+// are zeroed by the caller and their lanes never launched), or null / n_cols.
 template <int NS>
 __global__ void k_colsum_short_masked(const int64_t *__restrict__ t_rowptr, const float *__restrict__ t_raw, const uint16_t *__restrict__ mask,
-                                      float scale, int ns, int64_t n_cols, int long_row, float *__restrict__ out) {
+                                      float scale, int ns, int64_t n_cols, int long_row, const int32_t *__restrict__ list, int64_t n_slots,
+                                      float *__restrict__ out) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t j = gid >> 3;
+    const int64_t slot = gid >> 3;
+    const int64_t j = slot < n_slots ? (list ? (int64_t)list[slot] : slot) : n_cols;
     const int sub = (int)(gid & 7);
     float acc[NS];
 #pragma unroll
@@ -388,10 +392,15 @@ int gnx_graph_colsum_streams(gnx_graph_t g, float dropout_p, uint64_t seed, uint
             if (rc != GNX_OK) return rc;
             float *out = d_colsum_out + (int64_t)k0 * n;
             hipLaunchKernelGGL(k_keep_masks, dim3(blocks_for(t.nnz)), dim3(256), 0, s, g->t_rowidx, t.colidx, t.nnz, d, ns, g->t_mask);
+            // only the columns that have entries (ascending: the stores stay in order); the sums of the others are zero
+            const bool trim = t.nonempty_rows != nullptr && t.n_nonempty < t.n_rows;
+            const int64_t n_slots = trim ? t.n_nonempty : t.n_rows;
+            if (trim) GNX_HIP(hipMemsetAsync(out, 0, (size_t)ns * (size_t)n * sizeof(float), s));
+            const unsigned nbm = blocks_for(n_slots * 8);
 #define GNX_MASKED(NS)                                                                                                                 \
             do {                                                                                                                       \
-                hipLaunchKernelGGL(k_colsum_short_masked<NS>, dim3(nb), dim3(256), 0, s, t.rowptr, g->t_raw, g->t_mask, d.scale, ns,  \
-                                   t.n_rows, t.long_row, out);                                                                         \
+                hipLaunchKernelGGL(k_colsum_short_masked<NS>, dim3(nbm), dim3(256), 0, s, t.rowptr, g->t_raw, g->t_mask, d.scale, ns, \
+                                   t.n_rows, t.long_row, trim ? t.nonempty_rows : nullptr, n_slots, out);                              \
                 if (t.n_long > 0)                                                                                                      \
                     hipLaunchKernelGGL(k_colsum_long_masked<NS>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, g->t_raw,        \
                                        g->t_mask, d.scale, ns, t.long_rows, t.n_rows, out);                                            \
