@@ -97,6 +97,7 @@ def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout
     """``iterations`` PPR steps from H0 through the fused loop (what PPRLoop and a run of plain PPRIteration layers execute).
     Returns (result, run) with run(k) = the value after the first k iterations (for the intermediate layers' lazy ``.value``)."""
     training = graph_dropout != 0 and architecture.is_training()
+    cheap = True                                                # asking make_adj for an iteration's adjacency again costs nothing
     if training:
         seed, first = architecture._next_mask_stream(iterations)
         graph, p = architecture.graph, graph_dropout
@@ -114,6 +115,7 @@ def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout
                     kept[k] = sparse.normalize(graph, "symmetric", "none", p, seed, first + k)
                 return kept.pop(k) if bwd else kept[k]
         else:
+            cheap = False                                       # every call materialises an nnz-sized value array
             make_adj = lambda k, bwd=False: sparse.normalize(graph, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
     else:
         adj = architecture.get_adjacency(graph_dropout)
@@ -122,7 +124,7 @@ def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout
         run = lambda k: sparse.appnp_propagate(make_adj(0, False), H0_value, a, k)
     else:
         run = lambda k: sparse.ppr_loop(make_adj, H0_value, a, k)
-    return run(iterations), run
+    return run(iterations), run, (make_adj if cheap else None)
 
 
 class PPRIteration(Layer):
@@ -182,10 +184,12 @@ class PPRIteration(Layer):
             run.append(layer)
         if len(run) < 2:
             return None
-        out, upto = _propagation_run(architecture, features, float(self.restart_probability), len(run), self.graph_dropout)
+        out, upto, make_adj = _propagation_run(architecture, features, float(self.restart_probability), len(run), self.graph_dropout)
         for k, layer in enumerate(run[:-1]):
             layer.__dict__["_value"], layer.__dict__["_pending_value"] = None, (lambda k=k: upto(k + 1))
         run[-1].value = out
+        for k, layer in enumerate(run):                         # filter.py:18 leaves the iteration's adjacency in self.G
+            layer.G = make_adj(k, False) if make_adj is not None else None
         return len(run), out
 
 

@@ -881,6 +881,7 @@ def test_hand_built_ppr_iteration_stack_runs_fused(gnntf):
         its_f = [l for l in fused.layers() if isinstance(l, gnntf.PPRIteration)]
         its_p = [l for l in plain.layers() if isinstance(l, gnntf.PPRIteration)]
         assert torch.equal(its_f[-1].value, out_f)
+        assert all(l.G is fused.get_adjacency(0.5) for l in its_f)          # filter.py:18: every iteration's layer keeps its adjacency in .G
         for k in (0, 4, 8):                                       # an intermediate iteration's value: computed when read
             assert its_f[k].__dict__.get("_value") is None
             assert torch.equal(its_f[k].value, its_p[k].value)
