@@ -245,15 +245,27 @@ def measure_traffic_in_run(workloads, seconds=200.0):
             out = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", "python3", os.path.abspath(__file__),
                    "--workload", w, "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-secondary", "--pmc-in-run", "off"]
+            # the pass runs in a process group of its own, so that a pass that outlives its time limit can be ended WHOLE (profiler
+            # and the python under it): a survivor would keep tens of GB of the card this process is about to use
             try:
-                res = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                     text=True, timeout=max(30.0, seconds - (time.time() - t_start)))
+                errlog = open(os.path.join(tmp, ctr + ".err"), "w+")
+                child = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=errlog,
+                                         start_new_session=True)
+                try:
+                    rc = child.wait(timeout=max(30.0, seconds - (time.time() - t_start)))
+                except subprocess.TimeoutExpired:
+                    import signal
+                    os.killpg(child.pid, signal.SIGKILL)                  # (its own session: pgid == pid of the process started here)
+                    child.wait()
+                    problem = f"pass {ctr} exceeded its time limit and was ended"
+                    break
             except Exception as error:
                 problem = repr(error)[:200]
                 break
             found = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
-            if res.returncode != 0 or not found:
-                problem = f"pass {ctr} failed (rc {res.returncode}): " + (res.stderr or "")[-200:]
+            if rc != 0 or not found:
+                errlog.seek(0)
+                problem = f"pass {ctr} failed (rc {rc}): " + errlog.read()[-200:]
                 break
             csvs[ctr] = max(found, key=os.path.getmtime)
         if problem is None:
