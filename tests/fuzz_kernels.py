@@ -67,7 +67,9 @@ for case in range(cases):
                 assert torch.equal(D[k], gnntf.sparse.dropped_degree_scales(g, p, 5, case + k, 1)[0]), f"scales case {case} stream {k}"
             adjs = [gnntf.sparse.dropped_adjacency(g, p, 5, case + k, D=D[k]) for k in range(K)]
             tol = 2e-5 * (1.0 + np.sqrt(longest) / 10.0)
-            rel = lambda x, y: float(((x - y).abs() / y.abs().max(dim=1, keepdim=True).values.clamp_min(1e-3)).max())
+            # error relative to the row's largest element, but never to less than 1 % of the matrix's largest: a row whose terms
+            # cancel to ~1e-3 of their size (seed 303, case 1081: C = 1, |row| = 1.1e-3, terms ~ 1) carries the float32 noise of its terms
+            rel = lambda x, y: float(((x - y).abs() / y.abs().max(dim=1, keepdim=True).values.clamp_min(max(1e-3, 1e-2 * float(y.abs().max())))).max())
             with torch.no_grad():
                 f_got = gnntf.sparse.ppr_loop(lambda k, bwd=False: adjs[k], dev(H0), a_, K)
                 f_want = dev(H0)
@@ -80,7 +82,22 @@ for case in range(cases):
             for k in range(K - 1, -1, -1):
                 gk = _launch(adjs[k], gk, None, 1.0 - a_, 0.0, 0, transposed=True)
                 b_want = b_want + gk * (a_ if k >= 1 else 1.0)
-            assert rel(b_got, b_want) < tol, f"chained backward case {case}: {rel(b_got, b_want)}"
+            if rel(b_got, b_want) >= tol:      # which of the two is off?  float64 through the materialised dropped adjacencies decides
+                import scipy.sparse as sp
+                ref_g = X.astype(np.float64)
+                ref = a_ * ref_g
+                for k in range(K - 1, -1, -1):
+                    ai, av = orc.get_adjacency(idx, vals, (n, n), graph_dropout=p, training=True, seed=5, stream=case + k, dtype=np.float64)
+                    A = sp.csr_matrix((av, (ai[:, 0], ai[:, 1])), shape=(n, n))
+                    ref_g = (1.0 - a_) * (A.T @ ref_g)
+                    ref = ref + ref_g * (a_ if k >= 1 else 1.0)
+                ref_t = dev(ref.astype(np.float32))
+                e_chained, e_steps = rel(b_got, ref_t), rel(b_want, ref_t)
+                worst = int(((b_got - b_want).abs() / b_want.abs().max(dim=1, keepdim=True).values.clamp_min(max(1e-3, 1e-2 * float(b_want.abs().max())))).max(dim=1).values.argmax())
+                raise AssertionError(f"chained backward case {case}: chained vs steps {rel(b_got, b_want):.3e} (tol {tol:.3e}); vs float64: chained "
+                                     f"{e_chained:.3e}, steps {e_steps:.3e}; n={n} nnz={nnz} C={C} p={p} K={K} longest={longest} worst row {worst} "
+                                     f"deg {int(np.bincount(idx[:, 0], minlength=n)[worst])} max|want| {float(b_want[worst].abs().max()):.3e} "
+                                     f"max D {float(D.max()):.3e}")
             stats["dropped"] += 1
         elif kind == 2 and nnz:
             adj = gnntf.normalize(g, "symmetric")
