@@ -312,6 +312,7 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_m
            "traffic": traffic, "traffic_source": source, "min_rule_applied": bool(traffic) and not stale, "traffic_entry_inconsistent_with_this_run": stale,
            "frac_upper_bound": min(bound / HBM_PEAK_GBS, 1.0),
            "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
+           "frac_compulsory": (b_min / launch_s / 1e9 / HBM_PEAK_GBS) if b_min else None,
            "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K,
            "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if (measured_peak and achieved) else None,
            "measured_read_peak": read_peak,
@@ -319,8 +320,9 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_m
            "note": (what or "one launch = one fused SpMM+mix iteration incl. its long-row kernels") + "; achieved = min(B_alg, traffic) / launch time "
                    "(null when no PMC entry exists for this workload: frac_upper_bound = min(B_alg / t, in-run read-only stream) / peak is then all "
                    "that can be said); traffic = bytes leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE): Infinity-Cache hits are counted in it, so this is a "
-                   "fabric-level figure, not DRAM bandwidth; measured_peak = in-run device stream copy (read + write), measured_read_peak = in-run "
-                   "read-only stream (the SpMM is almost all reads)"}
+                   "fabric-level figure, not DRAM bandwidth (frac_compulsory = B_min / t / peak is the strictest reading: every array touched once); "
+                   "measured_peak = in-run device stream copy (read + write), measured_read_peak = in-run read-only stream (the SpMM is "
+                   "almost all reads)"}
     return rec
 
 
