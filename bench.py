@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--pmc-in-run", choices=["on", "off"], default="on",
                     help="N = 1: before anything else, run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (one step each, child "
                          "processes) so that roofline.traffic is measured in this run; off / failure: the committed profiles/pmc_traffic.json")
+    ap.add_argument("--gather-yardstick", choices=["on", "off"], default="on",
+                    help="N = 1: time the same kernel on a d-regular random graph of the same N and C (no reuse: B_alg is DRAM traffic there) and "
+                         "report it beside the roofline fraction")
+    ap.add_argument("--pmc-child", choices=["", "segments"], default="", help=argparse.SUPPRESS)    # run by measure_traffic_in_run under rocprofv3
     ap.add_argument("--whole-rows", action="store_true", help="do not split interior / boundary rows")
     ap.add_argument("--force-sharded", action="store_true", help="run the vertex-partitioned path even with one rank (rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
@@ -87,6 +91,13 @@ def alg_bytes_dropped_iteration(n, nnz, kept, C, backward=False):
     if backward:
         return nnz * 8 + kept * 4 * C + n * (4 + 4 + 4 + 12 * C)
     return nnz * 8 + kept * 4 * C + n * (4 + 4 + 4 + 8 * C)
+
+
+def min_bytes_dropped_iteration(n, nnz, C, backward=False):
+    """Compulsory bytes of one TRAINING iteration, every array touched once (the convention of min_bytes_per_iteration): col + raw
+    value of every stored entry, rowptr + D[row] + the next scale per row, the operand read once, H0 (forward) / the running sum
+    read and written (backward), the result written."""
+    return 8 * nnz + n * (4 + 4 + 4) + (16 if backward else 12) * n * C
 
 
 def kept_entries(g, p, seed, first_stream, n_streams):
@@ -220,12 +231,90 @@ def fabric_bytes_per_launch(fetch_csv, write_csv):
     return total
 
 
-def measure_traffic_in_run(workloads, seconds=200.0):
+SEGMENT_WIDTHS = (256, 128, 64, 40, 8, 7)       # widths propagated on the config-4 graph in the segments pass (256 = the roofline run; 40 / 7 =
+                                                  # the widths gnntf's own APPNP propagates on arxiv / Cora: filter.py:33-35, width = num_classes)
+TRAIN_WIDTH, TRAIN_LAUNCHES = 64, 3               # the training launches of the segments pass
+
+
+def segment_plan(K):
+    """[(traffic-table name, launches)] of the measured segments of `bench.py --pmc-child segments`, in order."""
+    n4, e4, _ = WORKLOADS["config4"]
+    wl = workload_name(n4, e4, TRAIN_WIDTH)
+    return [(workload_name(n4, e4, C), K) for C in SEGMENT_WIDTHS] + [("train_forward_" + wl, TRAIN_LAUNCHES), ("train_backward_" + wl, TRAIN_LAUNCHES)]
+
+
+def fabric_bytes_by_segment(fetch_csv, write_csv, marker="k_stream"):
+    """Bytes leaving the L2s per SEGMENT of a run that a marker kernel cuts into pieces (same corrections as fabric_bytes_per_launch:
+    KiB, reads doubled on gfx950; only the SpMM kernels are counted).  Returns {segment number: bytes}, segment s = the dispatches
+    between the s-th marker and the next one (0 = before the first marker)."""
+    import collections
+    import csv
+    total = collections.defaultdict(float)
+    for path, counter, factor in ((fetch_csv, "FETCH_SIZE", 2048.0), (write_csv, "WRITE_SIZE", 1024.0)):
+        rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Dispatch_Id"]))
+        seg, marks = 0, set()
+        for r in rows:
+            if marker in r["Kernel_Name"]:
+                if r["Dispatch_Id"] not in marks:                     # (one row per counter and dispatch)
+                    marks.add(r["Dispatch_Id"])
+                    seg += 1
+            elif r["Counter_Name"] == counter and "k_spmm" in r["Kernel_Name"]:
+                total[seg] += factor * float(r["Counter_Value"])
+    return dict(total)
+
+
+def pmc_segments_child(args, device):
+    """`bench.py --pmc-child segments` (run by measure_traffic_in_run under rocprofv3 --pmc, never by hand for a result): ONE
+    process on the config-4 graph in which a marker kernel (k_stream: a 64-float gnx_stream_read) brackets each measured piece --
+    the K-iteration propagation at every width of SEGMENT_WIDTHS, then TRAIN_LAUNCHES forward and backward training launches at
+    TRAIN_WIDTH -- each after an unmeasured warm-up of its own (lazily built handle parts).  Measured piece i is segment 2 i + 1."""
+    import torch
+    import gnntf
+    from gnntf import _native as nat
+    from gnntf import sparse as sp
+    lib = nat.lib()
+    K, a = args.iterations, args.alpha
+    n4, e4, _ = WORKLOADS["config4"]
+    g, adj, _ = build_single(argparse.Namespace(nodes=n4, entries=e4), device)
+    n = g.n_rows
+    mark_src, mark_sink = torch.zeros(64, device=device), torch.zeros(64, device=device)
+
+    def bracket(fn, launches=1):
+        fn()                                                                   # warm-up, outside the measured segment
+        torch.cuda.synchronize()
+        nat.check(lib.gnx_stream_read(nat.ptr(mark_src), 64, nat.ptr(mark_sink), nat.current_stream()))
+        for _ in range(launches):
+            fn()
+        nat.check(lib.gnx_stream_read(nat.ptr(mark_src), 64, nat.ptr(mark_sink), nat.current_stream()))
+        torch.cuda.synchronize()
+
+    for C in SEGMENT_WIDTHS:
+        gen = torch.Generator(device=device).manual_seed(2)
+        H0 = torch.rand(n, C, device=device, generator=gen) * 2 - 1
+        res, work = torch.empty_like(H0), torch.empty_like(H0)
+        bracket(lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(res), nat.ptr(work),
+                                                          nat.current_stream())))
+        del H0, res, work
+    C = TRAIN_WIDTH
+    X = torch.rand(n, C, device=device) * 2 - 1
+    gout = torch.rand(n, C, device=device)
+    scales = sp.dropped_degree_scales(g, 0.5, 1, 0, K)
+    adj1 = sp.dropped_adjacency(g, 0.5, 1, 1, D=scales[1])
+    with torch.no_grad():
+        bracket(lambda: sp._launch_chained(adj1, X, X, 1.0 - a, a, True, scales[2], skip_empty=True), TRAIN_LAUNCHES)
+        S_run, Y_run = torch.zeros_like(gout), torch.empty_like(gout)
+        bracket(lambda: sp._launch_back(adj1, gout, True, scales[0], S_run, 1.0, a * (1.0 - a), S_run, 1.0 - a, Y_run, skip_empty=True), TRAIN_LAUNCHES)
+    torch.cuda.synchronize()
+
+
+def measure_traffic_in_run(workloads, seconds=240.0, K=10):
     """rocprofv3 --pmc passes of THIS bench command, made by this process before it touches the GPU (child processes: the program
-    after `--` is the interpreter itself): FETCH_SIZE and WRITE_SIZE, one pass each, per workload -- one propagation step of the
-    same timed call on the same box.  Fills IN_RUN_TRAFFIC, so that roofline.traffic is measured in the driver's own run rather
-    than read from committed files; whatever fails (no rocprofv3, no counter access, time) leaves the committed entry in charge and
-    says so in the returned notes."""
+    after `--` is the interpreter itself): FETCH_SIZE and WRITE_SIZE, one pass each, per entry of ``workloads`` -- "config5" /
+    "config4": one propagation step of the same timed call on the same box; "segments": the config-4 graph at every width of
+    SEGMENT_WIDTHS plus the training launches, one process cut into segments by a marker kernel (pmc_segments_child).  Fills
+    IN_RUN_TRAFFIC, so that every roofline record's traffic is measured in the driver's own run rather than read from committed
+    files; whatever fails (no rocprofv3, no counter access, time) leaves the committed entries in charge and says so in the
+    returned notes."""
     import glob
     import shutil
     import tempfile
@@ -234,17 +323,18 @@ def measure_traffic_in_run(workloads, seconds=200.0):
         return {w: "rocprofv3 not on PATH" for w in workloads}
     t_start = time.time()
     for w in workloads:
-        n, e, C = WORKLOADS[w]
-        name = workload_name(n, e, C)
         tmp = tempfile.mkdtemp(prefix="gnx_pmc_", dir="/tmp")
         csvs, problem = {}, None
+        if w == "segments":
+            child_args = ["--pmc-child", "segments", "--iterations", str(K)]
+        else:
+            child_args = ["--workload", w, "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-secondary", "--pmc-in-run", "off", "--gather-yardstick", "off"]
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             if time.time() - t_start > seconds:
                 problem = "time budget spent"
                 break
             out = os.path.join(tmp, ctr)
-            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", "python3", os.path.abspath(__file__),
-                   "--workload", w, "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-secondary", "--pmc-in-run", "off"]
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", "python3", os.path.abspath(__file__)] + child_args
             # the pass runs in a process group of its own, so that a pass that outlives its time limit can be ended WHOLE (profiler
             # and the python under it): a survivor would keep tens of GB of the card this process is about to use
             try:
@@ -268,20 +358,31 @@ def measure_traffic_in_run(workloads, seconds=200.0):
                 problem = f"pass {ctr} failed (rc {rc}): " + errlog.read()[-200:]
                 break
             csvs[ctr] = max(found, key=os.path.getmtime)
-        if problem is None:
+        how = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py " + " ".join(child_args) + "`, run by THIS bench process on " \
+              "this box before its timed region (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, per launch)"
+        if problem is None and w == "segments":
+            try:
+                by_segment = fabric_bytes_by_segment(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"])
+                for i, (name, launches) in enumerate(segment_plan(K)):
+                    if by_segment.get(2 * i + 1):
+                        IN_RUN_TRAFFIC[name] = (by_segment[2 * i + 1] / launches, how)
+                missing = [name for name, _ in segment_plan(K) if name not in IN_RUN_TRAFFIC]
+                notes[w] = "measured in this run" if not missing else "measured in this run except " + ", ".join(missing)
+            except Exception as error:
+                problem = repr(error)[:200]
+        elif problem is None:
+            n, e, C = WORKLOADS[w]
             try:
                 total = fabric_bytes_per_launch(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"])
             except Exception as error:
                 total, problem = None, repr(error)[:200]
             if total:
-                IN_RUN_TRAFFIC[name] = (total, "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py --workload " + w +
-                                        " --steps 1 --warmup 0 --cpu-seconds 0 --no-secondary`, run by THIS bench process on this box before its timed "
-                                        "region (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes, per launch)")
+                IN_RUN_TRAFFIC[workload_name(n, e, C)] = (total, how)
                 notes[w] = "measured in this run"
             elif problem is None:
                 problem = "no SpMM dispatch in the counter files"
         if problem is not None:
-            notes[w] = "not measured in this run (" + problem + "): the committed entry of profiles/pmc_traffic.json is used"
+            notes[w] = "not measured in this run (" + problem + "): the committed entries of profiles/pmc_traffic.json are used"
         shutil.rmtree(tmp, ignore_errors=True)
     notes["seconds"] = round(time.time() - t_start, 1)
     return notes
@@ -290,11 +391,18 @@ def measure_traffic_in_run(workloads, seconds=200.0):
 MEASURED_READ_PEAK = [None]        # in-run read-only streaming rate (set once by main)
 
 
+FRAC_LEVEL = "fabric: bytes leaving the L2s, Infinity-Cache hits included -- NOT DRAM bandwidth (dram_frac_* and no_reuse_gather_* are)"
+
+
 def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_min=None, what=None):
     """achieved = min(B_alg, B_rocprof) / t per launch; B_alg, B_min, B_rocprof and t printed together.
-    Without a committed PMC entry for ``name`` the min() cannot be taken: ``achieved`` / ``frac`` are then null
-    (``min_rule_applied`` false) and only an upper bound is given -- B_alg / t capped at the in-run read-only stream rate -- so that
-    no line can carry a fraction the counters have not bounded (or one above 1)."""
+    ``frac`` is a FABRIC-level figure (``frac_level``): the counters see what leaves the L2s, and the Infinity Cache serves part of
+    it.  What can be said about DRAM itself is carried beside it: ``dram_frac_lower_bound`` (every array touched once: B_min / t /
+    peak) and ``dram_frac_upper_bound`` (DRAM cannot have moved more than the fabric did, nor faster than this box streams reads
+    in this run) -- the fabric figure is never below either -- and, once add_gather_ceiling has run, the rate of the same kernel
+    on a graph WITHOUT reuse, where fabric bytes are DRAM bytes.
+    Without a PMC entry for ``name`` the min() cannot be taken: ``achieved`` / ``frac`` are null (``min_rule_applied`` false) and
+    ``frac_bound_without_counters`` = min(B_alg / t, in-run read stream) / peak is all that is printed."""
     if b_alg is None:
         b_alg, b_min = alg_bytes_per_iteration(n, nnz, C), min_bytes_per_iteration(n, nnz, C)
     traffic, source = pmc_traffic(name)
@@ -307,23 +415,76 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_m
             achieved, frac, stale = None, None, True
     else:
         achieved = frac = None
-    bound = min(b_alg / launch_s / 1e9, read_peak if read_peak else HBM_PEAK_GBS)
-    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
-           "traffic": traffic, "traffic_source": source, "min_rule_applied": bool(traffic) and not stale, "traffic_entry_inconsistent_with_this_run": stale,
-           "frac_upper_bound": min(bound / HBM_PEAK_GBS, 1.0),
+    read_frac = (read_peak if read_peak else HBM_PEAK_GBS) / HBM_PEAK_GBS
+    compulsory = (b_min / launch_s / 1e9 / HBM_PEAK_GBS) if b_min else None
+    rec = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, "frac_level": FRAC_LEVEL,
+           "traffic": traffic, "traffic_source": source, "traffic_in_run": bool(source) and "THIS bench process" in source,
+           "min_rule_applied": bool(traffic) and not stale, "traffic_entry_inconsistent_with_this_run": stale,
+           "frac_bound_without_counters": None if frac is not None else min(b_alg / launch_s / 1e9 / HBM_PEAK_GBS, read_frac, 1.0),
            "alg_bytes_per_launch": b_alg, "min_bytes_per_launch": b_min,
-           "frac_compulsory": (b_min / launch_s / 1e9 / HBM_PEAK_GBS) if b_min else None,
+           "frac_compulsory": compulsory, "dram_frac_lower_bound": compulsory,
+           "dram_frac_upper_bound": min(frac, read_frac) if frac is not None else None,
            "launch_ms": launch_s * 1e3, "t_prop_ms": launch_s * 1e3 * K,
-           "measured_peak": measured_peak, "frac_of_measured_peak": (achieved / measured_peak) if (measured_peak and achieved) else None,
-           "measured_read_peak": read_peak,
-           "frac_of_measured_read_peak": (achieved / read_peak) if (read_peak and achieved) else None,
-           "note": (what or "one launch = one fused SpMM+mix iteration incl. its long-row kernels") + "; achieved = min(B_alg, traffic) / launch time "
-                   "(null when no PMC entry exists for this workload: frac_upper_bound = min(B_alg / t, in-run read-only stream) / peak is then all "
-                   "that can be said); traffic = bytes leaving the L2s (FETCH_SIZE x2 + WRITE_SIZE): Infinity-Cache hits are counted in it, so this is a "
-                   "fabric-level figure, not DRAM bandwidth (frac_compulsory = B_min / t / peak is the strictest reading: every array touched once); "
-                   "measured_peak = in-run device stream copy (read + write), measured_read_peak = in-run read-only stream (the SpMM is "
-                   "almost all reads)"}
+           "measured_peak": measured_peak, "measured_read_peak": read_peak,
+           "fabric_rate_over_read_stream": (achieved / read_peak) if (read_peak and achieved) else None,
+           "no_reuse_gather_GBs": None, "no_reuse_gather_frac": None, "frac_of_gather_ceiling": None,
+           "note": (what or "one launch = one fused SpMM+mix iteration incl. its long-row kernels") + "; achieved = min(B_alg, traffic) / launch time; "
+                   "traffic = FETCH_SIZE x2 + WRITE_SIZE (separate --pmc passes): bytes leaving the L2s, a fabric-level figure (Infinity-Cache hits "
+                   "counted; fabric_rate_over_read_stream > 1 shows them); DRAM moved between dram_frac_lower_bound (B_min / t / peak) and "
+                   "dram_frac_upper_bound (min(frac, in-run read stream / peak)); no_reuse_gather_*: the same kernel on a d-regular random graph "
+                   "of the same N and C, where nothing is reused and B_alg IS the DRAM traffic; measured_peak = in-run stream copy, "
+                   "measured_read_peak = in-run read-only stream"}
     return rec
+
+
+def gather_yardstick(device, n, C, a=0.1, d=16):
+    """The no-reuse gather ceiling, measured in this run: one fused SpMM+mix launch over a graph whose every row has ``d`` uniformly
+    random neighbours (tools/regular_sweep.py's graph) at the SAME N and C.  N * C * 4 bytes is far beyond the 256 MB Infinity
+    Cache and no row is gathered more often than any other, so B_alg / t of THIS launch is a DRAM-level rate: what the chip gathers
+    whole random rows at.  R-MAT's figure above it is the hub rows served on-die."""
+    import torch
+    import gnntf
+    from gnntf.sparse import _launch
+    rows = torch.arange(n, device=device).repeat_interleave(d)
+    cols = torch.randint(0, n, (n * d,), device=device)
+    idx = torch.stack([rows, cols], 1)
+    del rows, cols
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=device), (n, n)), device=device)
+    del idx
+    torch.cuda.empty_cache()
+    adj = gnntf.Adjacency(g)
+    H, H0 = torch.rand(n, C, device=device), torch.rand(n, C, device=device)
+    out = torch.empty_like(H)
+    ms = median_ms(lambda: _launch(adj, H, H0, 1.0 - a, a, 0, out=out), reps=3, warm=1)
+    rec = {"GBs": alg_bytes_per_iteration(n, g.nnz, C) / ms / 1e6, "launch_ms": ms, "rows": n, "entries": g.nnz, "d": d, "C": C, "kernel": g.last_kernel()}
+    del g, adj, H, H0, out
+    torch.cuda.empty_cache()
+    return rec
+
+
+def add_gather_ceiling(rec, yard):
+    """Puts the in-run no-reuse yardstick beside a roofline record: the DRAM-level rate of the kernel where it can be measured
+    (no_reuse_gather_frac = that / peak), and the record's own rate relative to it (above 1 = reuse served on-die)."""
+    if yard:
+        rec["no_reuse_gather_GBs"] = yard["GBs"]
+        rec["no_reuse_gather_frac"] = yard["GBs"] / HBM_PEAK_GBS
+        rec["no_reuse_gather_launch_ms"] = yard["launch_ms"]
+        rec["no_reuse_gather_entries"] = yard["entries"]
+        if rec.get("achieved"):
+            rec["frac_of_gather_ceiling"] = rec["achieved"] / yard["GBs"]
+    return rec
+
+
+FLAT_KEYS = ("ms_per_step", "launch_ms", "frac", "achieved", "traffic", "traffic_in_run", "alg_bytes_per_launch", "min_bytes_per_launch",
+             "frac_compulsory", "dram_frac_upper_bound", "no_reuse_gather_frac", "frac_of_gather_ceiling", "edges_per_s")
+
+
+def flat_keys(prefix, rec, **extra):
+    """A secondary roofline record as FLAT scalar keys (``<prefix>_frac``, ``<prefix>_traffic`` ...) for the primary line's
+    ``roofline`` object: the driver's record keeps flat scalars of that object and drops nested ones, and the line's tail is
+    truncated -- so the roofline run (config 4) and the narrow widths must be recomputable from these keys alone."""
+    both = dict(rec, **extra)
+    return {f"{prefix}_{k}": both[k] for k in FLAT_KEYS if both.get(k) is not None}
 
 
 # ---- CPU baselines on a bounded sample: SURVEY.md 8(d) (i) scipy, one thread; (ii) torch.sparse.mm, all threads; (iii) C / OpenMP port ----
@@ -426,23 +587,32 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     g, adj, prep = build_single(argparse.Namespace(nodes=n4, entries=e4), device)
     n, nnz = g.n_rows, g.nnz
     widths = []
-    for C in ([] if skip_config4 else [c4]) + [128, 64, 8]:
+    flat = {}                                                    # flat scalar copies for the primary line's roofline object (flat_keys)
+    yard = None
+    if args.gather_yardstick == "on":
+        yard = gather_yardstick(device, n4, c4, a)
+        out["config4_no_reuse_gather_yardstick"] = yard
+    for C in ([] if skip_config4 else [c4]) + [w for w in SEGMENT_WIDTHS if w != c4]:
         gen = torch.Generator(device=device).manual_seed(2)
         H0 = torch.rand(n, C, device=device, generator=gen) * 2 - 1
         res, work = torch.empty_like(H0), torch.empty_like(H0)
         ms = median_ms(lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(res),
                                                                  nat.ptr(work), nat.current_stream())), reps=3, warm=1)
-        rec = {"C": C, "kernel": g.last_kernel(), "ms_per_step": ms, "edges_per_s": nnz * K / ms * 1e3,
-               "roofline": roofline_record(n, nnz, C, ms * 1e-3 / K, K, workload_name(n4, e4, C), measured_peak)}
+        roof = roofline_record(n, nnz, C, ms * 1e-3 / K, K, workload_name(n4, e4, C), measured_peak)
+        rec = {"C": C, "kernel": g.last_kernel(), "ms_per_step": ms, "edges_per_s": nnz * K / ms * 1e3, "roofline": roof}
         if C == c4:
+            add_gather_ceiling(roof, yard)
             out["config4_roofline_run"] = dict(rec, workload=workload_name(n4, e4, C) + f"_appnp_K{K}", prep=prep)
+            flat.update(flat_keys("config4", roof, ms_per_step=ms, edges_per_s=rec["edges_per_s"]))
+            flat.update(config4_workload=workload_name(n4, e4, C) + f"_appnp_K{K}", config4_rows=n, config4_entries=nnz, config4_kernel=rec["kernel"])
         else:
             widths.append(rec)
+            flat.update(flat_keys(f"config4_graph_C{C}", roof, ms_per_step=ms, edges_per_s=rec["edges_per_s"]))
         del H0, res, work
     out["config4_graph_other_widths"] = widths
     # the same propagation through the API the north star names: architecture.predict() of gnntf.APPNP (filter.py:25-35 ->
-    # trainable.py:26-29) on the config-4 graph.  APPNP builds [Dropout, Dense(F -> C), PPRLoop]; the PPRLoop layer's forward, called
-    # through the Layer protocol in eval mode, is the K = 10 propagation at width C and must cost what gnx_appnp_propagate costs
+    # trainable.py:26-29) on the config-4 graph.  APPNP builds filter.py:30-35's own list [Dropout, Dense(F -> C), K x PPRIteration]; the
+    # container executes the K layers as one fused run, which must cost what gnx_appnp_propagate costs and return the same bits
     via_api = []
     for C in ([] if skip_config4 else [c4]) + [8]:
         gnntf.set_seed(0)
@@ -457,23 +627,28 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         def predict():
             model._fast_predict = None                           # trainable.py:22-24: what reset() clears; every call recomputes
             return model.predict(task)
-        loop = model.layers()[-1]
+        first = len(model.layers()) - K                          # index of the first PPRIteration layer
         with torch.no_grad():
             t_predict = median_ms(predict, reps=3, warm=1)
-            H0 = loop.H0.value
-            t_loop = median_ms(lambda: loop(model, H0), reps=3, warm=1)
+            H0 = model.layers()[first - 1].value
+            t_loop = median_ms(lambda: model.run(H0, first=first), reps=3, warm=1)
             kernel = g.last_kernel()
             res, work = torch.empty_like(H0), torch.empty_like(H0)
             t_direct = median_ms(lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(res),
                                                                            nat.ptr(work), nat.current_stream())), reps=3, warm=1)
-            same = bool(torch.equal(loop.value, res))
-        via_api.append({"C": C, "layers": [type(l).__name__ for l in model.layers()], "predict_ms": t_predict, "ppr_loop_layer_ms": t_loop,
-                        "gnx_appnp_propagate_ms": t_direct, "layer_over_direct": t_loop / t_direct, "bitwise_equal": same, "kernel": kernel,
-                        "edges_per_s_layer": nnz * K / t_loop * 1e3,
-                        "what": f"gnntf.APPNP(graph, X[N, {F}], num_classes={C}, latent_dims=[]) in eval mode: predict_ms = architecture.predict(NodeClassification("
-                                f"100k nodes)) with the memo cleared (Dense {F} -> {C} on the matrix cores + K = {K} propagation + gather/argmax); "
-                                f"ppr_loop_layer_ms = the PPRLoop layer's forward alone; gnx_appnp_propagate_ms = the C entry on the same H0"})
-        del model, H0, res, work, task, nodes, loop
+            same = bool(torch.equal(model.layers()[-1].value, res))
+        via_api.append({"C": C, "layers": [type(l).__name__ for l in model.layers()], "n_layers": len(model.layers()), "predict_ms": t_predict,
+                        "propagation_layers_ms": t_loop,
+                        "gnx_appnp_propagate_ms": t_direct, "layers_over_direct": t_loop / t_direct, "bitwise_equal": same, "kernel": kernel,
+                        "edges_per_s_layers": nnz * K / t_loop * 1e3,
+                        "what": f"gnntf.APPNP(graph, X[N, {F}], num_classes={C}, latent_dims=[]) in eval mode, the reference's layer list: predict_ms = "
+                                f"architecture.predict(NodeClassification(100k nodes)) with the memo cleared (Dense {F} -> {C} on the matrix cores + K = {K} "
+                                f"propagation + gather/argmax); propagation_layers_ms = the K PPRIteration layers alone (architecture.run(H0, first=...)); "
+                                f"gnx_appnp_propagate_ms = the C entry on the same H0"})
+        flat.update({f"config4_C{C}_via_layers_ms": t_loop, f"config4_C{C}_c_entry_ms": t_direct, f"config4_C{C}_layers_bitwise_equal_c_entry": same})
+        for layer in model.layers():
+            layer.value = None
+        del model, H0, res, work, task, nodes
         torch.cuda.empty_cache()
         # the same propagation as user code builds it (reference demos/custom_layers.py:8-13): a Dense and K hand-added
         # PPRIteration(H0, a) layers.  The container runs them as one fused loop (Layer.__run__); fuse_runs = False is the
@@ -500,7 +675,7 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
                                            "max_abs_difference_to_layer_by_layer": float((fused_out - by_layer).abs().max()),
                                            "what": f"GNN(graph, X) + Dense({C}) + {K} x PPRIteration(H0, {a}) added by hand, eval mode: forward_ms with the "
                                                    f"container fusing the run (propagation_ms = forward - the Dense alone: to be compared with "
-                                                   f"ppr_loop_layer_ms), layer_by_layer_forward_ms with fuse_runs = False"}
+                                                   f"propagation_layers_ms), layer_by_layer_forward_ms with fuse_runs = False"}
         del hand, H0l, X, fused_out, by_layer
         torch.cuda.empty_cache()
     out["config4_via_layer_api"] = via_api
@@ -536,13 +711,17 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         ms_d = median_ms(lambda: sp.dropped_degree_scales(g, 0.5, 1, 0, K), reps=3, warm=1)
     wl = workload_name(n4, e4, C)
     roof_f = roofline_record(n, nnz, C, ms_f * 1e-3, K, "train_forward_" + wl, measured_peak,
-                             b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C), what="one forward TRAINING iteration (gnx_spmm_dropped_chained, "
+                             b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C), b_min=min_bytes_dropped_iteration(n, nnz, C),
+                             what="one forward TRAINING iteration (gnx_spmm_dropped_chained, "
                              "a middle one: weights from the counter RNG inside the SpMM, only kept entries gathered, rows without entries left to the last "
                              "iteration) incl. its long-row kernels")
     roof_b = roofline_record(n, nnz, C, ms_b * 1e-3, K, "train_backward_" + wl, measured_peak,
-                             b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True), what="one backward TRAINING iteration "
+                             b_alg=alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True), b_min=min_bytes_dropped_iteration(n, nnz, C, backward=True),
+                             what="one backward TRAINING iteration "
                              "(gnx_spmm_dropped_back over the transposed structure: the running gradient sum updated and the next step's "
                              "pre-scaled operand written in the epilogue) incl. its long-row kernels")
+    flat.update(flat_keys("train_C64_forward", roof_f), **flat_keys("train_C64_backward", roof_b))
+    flat.update(train_C64_step_ms=ms, train_C64_kept_entries=kept)
     out["training_step_C64"] = {"ms": ms, "two_pass_ms": ms2, "edges_per_s": 2 * nnz * K / ms * 1e3,
                                 "forward_launch_ms": ms_f, "backward_launch_ms": ms_b, "degree_scales_all_streams_ms": ms_d,
                                 "launches_share_of_step": (K * (ms_f + ms_b) + ms_d) / ms, "kept_entries": kept, "kernel": kernel_f,
@@ -640,6 +819,7 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     out["config2_cora_shaped_appnp"] = cora
     out["config3_arxiv_shaped_gcn"] = {"nodes": g3.n_rows, "entries": g3.nnz, "forward_ms": t_fwd, "spmm128_ms": t128, "spmm64_ms": t64,
                                        "spmm128_edges_per_s": g3.nnz / t128 * 1e3, "spmm64_edges_per_s": g3.nnz / t64 * 1e3}
+    out["flat"] = flat
     return out
 
 
@@ -698,14 +878,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     start_heartbeat()
     pmc_notes = None
-    if world == 1 and args.gpus == 1 and args.pmc_in_run == "on" and not args.force_sharded and args.workload in WORKLOADS \
+    if world == 1 and args.gpus == 1 and args.pmc_in_run == "on" and not args.pmc_child and not args.force_sharded and args.workload in WORKLOADS \
             and os.environ.get("GNX_BENCH_PMC", "1") != "0" and not any(k.startswith("ROCPROF") for k in os.environ) \
             and "rocprof" not in os.environ.get("LD_PRELOAD", ""):          # (never from inside a profiler run)
         # (nothing in this process has touched the GPU yet: the passes are child processes that come and go before it does)
-        wanted = [args.workload] + (["config4"] if args.workload != "config4" and not args.no_secondary else [])
-        note("counter passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one step each): " + ", ".join(wanted))
+        # the headline workload as its own command; everything on the config-4 graph (the roofline run at C = 256, the other widths,
+        # the training launches) in ONE further process cut into segments by a marker kernel
+        wanted = [args.workload] + (["segments"] if not args.no_secondary else [])
+        note("counter passes of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, child processes): " + ", ".join(wanted))
         t_ph = time.time()
-        pmc_notes = measure_traffic_in_run(wanted)
+        pmc_notes = measure_traffic_in_run(wanted, K=args.iterations)
         phase("pmc_passes_in_run", t_ph)
         note(f"counter passes: {pmc_notes}")
     if world != args.gpus:
@@ -726,6 +908,9 @@ def main():
     device = torch.device("cuda", local_rank)
     import gnntf
     gnntf.set_default_device(device)
+    if args.pmc_child == "segments":
+        pmc_segments_child(args, device)
+        return
     K, C, a = args.iterations, args.feats, args.alpha
     sharded_path = world > 1 or args.force_sharded
     pv, pf = world, 1
@@ -753,23 +938,27 @@ def main():
         H0 = torch.rand(n_local, C, device=device, generator=gen) * 2 - 1       # U(-1, 1), seed 2
         from gnntf import _native as nat
         lib = nat.lib()
-        # The timed step goes through the API the north star names: the propagation layer of gnntf.APPNP (filter.py:25-35), called
-        # through the Layer protocol in eval mode exactly as architecture.predict() calls it (trainable.py:26-29 -> layered.py:52-55).
-        # H0 stands for the pre-MLP's output: it is planted as the value of the Dense layer the loop reads.
+        # The timed step goes through the API the north star names: gnntf.APPNP (filter.py:25-35) with the reference's own layer list
+        # [Dropout, Dense, K x PPRIteration], its K propagation layers executed by the container's loop in eval mode exactly as
+        # architecture.predict() executes them (trainable.py:26-29 -> layered.py:52-55; Layered.run continues that loop from a value
+        # the caller holds).  H0 stands for the pre-MLP's output: it is planted as the value of the Dense layer
+        # the iterations read.
         gnntf.set_seed(0)
         model = gnntf.APPNP(g, torch.zeros(n_local, 1, device=device), num_classes=C, latent_dims=[], iterations=K, a=a)
         model.training_mode(False)
-        loop = model.layers()[-1]
-        assert isinstance(loop, gnntf.PPRLoop)
-        loop.H0.value = H0
-        api = {"timed_call": "PPRLoop.__call__(architecture, H0) -- the layer gnntf.APPNP(...) builds for filter.py:34-35, eval mode, torch.no_grad()",
-               "layers": [type(l).__name__ for l in model.layers()]}
-        adj = model.get_adjacency(0.5)                                          # the cached eval-mode adjacency the layer uses (A2 once)
+        first = len(model.layers()) - K
+        iters, pre = model.layers()[first:], model.layers()[first - 1]
+        assert all(type(l) is gnntf.PPRIteration for l in iters) and len(model.layers()) == 2 + K
+        pre.value = H0
+        api = {"timed_call": "architecture.run(H0, first=2): the K PPRIteration layers of gnntf.APPNP(...) (filter.py:34-35) through the container's loop, "
+                             "eval mode, torch.no_grad()",
+               "layers": [type(l).__name__ for l in model.layers()], "n_layers": len(model.layers())}
+        adj = model.get_adjacency(0.5)                                          # the cached eval-mode adjacency the layers use (A2 once)
 
         def step():
-            loop.value = None                                                   # (the previous result: 41 GB at config 5)
+            iters[-1].value = None                                              # (the previous result: 41 GB at config 5)
             with torch.no_grad():
-                loop(model, H0)
+                model.run(H0, first=first)
         halo = None
         C_local = C
     else:
@@ -938,21 +1127,21 @@ def main():
         direct = lambda: nat.check(lib.gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), None, nat.ptr(H0), a, K, C, nat.ptr(out), nat.ptr(work),
                                                            nat.current_stream()))
         api["gnx_appnp_propagate_ms_per_step"] = median_ms(direct, reps=3, warm=1)
-        api["layer_ms_per_step"] = sum(step_ms) / len(step_ms)
-        api["bitwise_equal_to_c_entry"] = bool(torch.equal(loop.value, out))
-        loop.value = None
+        api["layers_ms_per_step"] = sum(step_ms) / len(step_ms)
+        api["bitwise_equal_to_c_entry"] = bool(torch.equal(iters[-1].value, out))
+        iters[-1].value = None
         del out, work, direct
         torch.cuda.empty_cache()
         deg = torch.empty(g.n_rows, dtype=torch.float32, device=device)
         nat.check(lib.gnx_graph_colsum(g.handle, 0.0, 0, 0, nat.ptr(deg), nat.current_stream()))
         E0 = deg.sqrt()[:, None] * (1.0 + torch.arange(C, dtype=torch.float32, device=device) / C)[None, :]
         del deg
-        loop.H0.value = E0
+        pre.value = E0
         with torch.no_grad():
-            loop(model, E0)
+            model.run(E0, first=first)
         from gnntf.sharded import max_relative_deviation
-        check_err = max_relative_deviation(loop.value, E0)
-        loop.value, loop.H0.value = None, H0
+        check_err = max_relative_deviation(iters[-1].value, E0)
+        iters[-1].value, pre.value = None, H0
         del E0
     self_check = {"what": "H0 = sqrt(degree) x s_c is a fixed point of H <- (1-a) A_hat H + a H0 on a symmetric graph: largest deviation "
                           "after K iterations through the timed path, relative to max(|H0|, 1), max over ranks",
@@ -1042,12 +1231,23 @@ def main():
             phase("cpu_baseline", t_ph)
         else:
             result["cpu_baseline"] = None
-        if not sharded_path and not args.no_secondary:
-            del g, adj, H0, model, loop
+        if not sharded_path:
+            for layer in model.layers():
+                layer.value = None
+            del g, adj, H0, model, iters, pre, layer
             torch.cuda.empty_cache()
+            if args.gather_yardstick == "on":
+                note("no-reuse gather yardstick (d-regular random graph of the same N and C)")
+                t_ph = time.time()
+                yard = gather_yardstick(device, args.nodes, C, a)
+                add_gather_ceiling(roof, yard)
+                result["config"]["no_reuse_gather_yardstick"] = yard
+                phase("gather_yardstick", t_ph)
+        if not sharded_path and not args.no_secondary:
             note("secondary workloads")
             t_ph = time.time()
             result["secondary"] = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4")
+            roof.update(result["secondary"].pop("flat"))       # config 4, the other widths and the training launches as flat scalar keys
             phase("secondary_workloads", t_ph)
         PHASES["total"] = round(time.time() - T_START, 2)
         os.write(json_fd, (json.dumps(result) + "\n").encode())

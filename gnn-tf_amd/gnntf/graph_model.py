@@ -197,8 +197,9 @@ class PPRLoop(Layer):
     """``iterations`` PPRIteration layers (filter.py:34-35) collapsed into one layer and one autograd node:
     same arithmetic and the same sequence of edge-dropout masks as the layer-by-layer form, but no
     per-iteration ``.value`` tensors and no stored activations for the backward (they are not needed: the
-    step is linear in H, and dropped adjacencies are regenerated from the counter RNG).  What ``APPNP(...)`` builds by default;
-    only the default identity activation / zero feature dropout can be fused (``APPNP(..., fused=False)`` keeps the layers)."""
+    step is linear in H, and dropped adjacencies are regenerated from the counter RNG).  What ``APPNP(..., fused=True)`` builds (an
+    explicit opt-in: the default keeps the reference's layer list and fuses at execution, PPRIteration.__run__); only the default
+    identity activation / zero feature dropout can be collapsed."""
 
     def __build__(self, architecture: GNN, H0: Layer, restart_probability: float = 0.1, iterations: int = 10,
                   graph_dropout: float = 0.5):
@@ -216,21 +217,22 @@ class APPNP(GNN):
     """filter.py:25-35 -- https://arxiv.org/pdf/1810.05997.pdf"""
 
     def __init__(self, G, features, num_classes: int, a: float = 0.1, latent_dims=[64], iterations=10,
-                 dropout=0.6, graph_dropout=0.5, activation=linear, fused=None, **kwargs):
-        """``fused`` (not in the reference): the K PPRIteration layers of filter.py:34-35 as ONE PPRLoop layer -- the same arithmetic
-        and the same sequence of edge-dropout masks, bit for bit (tests), without K ``.value`` tensors of N x C floats and with
-        what only a loop can do (settled rows skipped, the relabelled copy at narrow widths, line-friendly padded widths).
-        Default (None): fused whenever the layers allow it -- a float restart probability and the identity activation, i.e.
-        filter.py's own defaults; ``fused=False`` keeps one layer per iteration (each with its ``.value``)."""
+                 dropout=0.6, graph_dropout=0.5, activation=linear, fused=False, **kwargs):
+        """Builds filter.py:30-35's layer list as it stands there: Dropout(0.5), one Dense per latent width, the output Dense (= H0),
+        then ``iterations`` PPRIteration layers -- ``layers()`` has the reference's length, order and types, every iteration its own
+        ``.value`` / ``.G``.  The container EXECUTES the run of plain PPRIteration layers as one fused loop (PPRIteration.__run__:
+        same arithmetic, same sequence of edge-dropout masks, one autograd node in training mode; settled rows skipped, the relabelled
+        copy at narrow widths, line-friendly padded widths), so the list costs what the collapsed form costs.
+        ``fused=True`` (not in the reference) collapses the iterations into ONE PPRLoop layer explicitly: no per-iteration layer
+        objects at all; needs a float restart probability and the identity activation."""
         super().__init__(G, features, **kwargs)
         self.add(Dropout(0.5))
         for latent_dim in latent_dims:
             self.add(Dense(latent_dim, activation=relu, dropout=dropout))
         H0 = self.add(Dense(num_classes, regularize=False))
-        fusable = a is not None and not isinstance(a, torch.Tensor) and activation is linear
-        if fused and not fusable:
-            raise Exception("APPNP(fused=True) needs a float restart probability and the identity activation")
-        if fusable and fused is not False:
+        if fused:
+            if a is None or isinstance(a, torch.Tensor) or activation is not linear:
+                raise Exception("APPNP(fused=True) needs a float restart probability and the identity activation")
             self.add(PPRLoop(H0, a, iterations, graph_dropout=graph_dropout))
             return
         for _ in range(iterations):

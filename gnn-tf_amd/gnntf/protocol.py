@@ -94,7 +94,13 @@ class Layered(VariableGenerator):
     fuse_runs = True                             # let layers execute runs of their kind in one go (Layer.__run__); False: strictly layer by layer
 
     def __call__(self, features):
-        stack, at = self._stack, 0
+        return self.run(features)
+
+    def run(self, features, first=0):
+        """The container's loop (layered.py:52-55) from layer index ``first`` on: ``run(x)`` is ``__call__(x)``; ``run(h, first=i)``
+        continues from a value of layer ``i - 1`` the caller already holds (not in the reference: benchmarks time the propagation
+        layers of a model through it without re-running the pre-MLP)."""
+        stack, at = self._stack, first
         while at < len(stack):                   # layered.py:52-55, except that a layer may take the ones that follow it along
             done = stack[at].__run__(self, features, stack, at) if self.fuse_runs else None
             if done is None:

@@ -24,12 +24,13 @@ def test_without_a_pmc_entry_no_fraction_is_claimed(traffic_table):
     b_alg = bench.alg_bytes_per_iteration(n, nnz, C)
     rec = bench.roofline_record(n, nnz, C, b_alg / 9.0e12, 10, "rmat_block_of_8", 5600.0)        # B_alg / t = 9 TB/s: above the peak
     assert rec["traffic"] is None and rec["achieved"] is None and rec["frac"] is None
-    assert rec["min_rule_applied"] is False
-    assert rec["frac_upper_bound"] == pytest.approx(7000.0 / 8000.0)                               # capped at the in-run read stream
-    assert rec["frac_of_measured_peak"] is None and rec["frac_of_measured_read_peak"] is None
+    assert rec["min_rule_applied"] is False and rec["traffic_in_run"] is False
+    assert rec["frac_bound_without_counters"] == pytest.approx(7000.0 / 8000.0)                    # capped at the in-run read stream
+    assert rec["fabric_rate_over_read_stream"] is None and rec["dram_frac_upper_bound"] is None
+    assert "frac_upper_bound" not in rec                                                           # (round 4's name: it sat BELOW frac)
     json.dumps(rec)
     slow = bench.roofline_record(n, nnz, C, b_alg / 2.0e12, 10, "rmat_block_of_8", 5600.0)
-    assert slow["frac"] is None and slow["frac_upper_bound"] == pytest.approx(0.25)
+    assert slow["frac"] is None and slow["frac_bound_without_counters"] == pytest.approx(0.25)
 
 
 def test_with_a_pmc_entry_the_min_rule_holds(traffic_table):
@@ -50,7 +51,77 @@ def test_a_fraction_above_one_is_never_printed(traffic_table):
     traffic_table["w"] = b_alg
     rec = bench.roofline_record(n, nnz, C, b_alg / 9.5e12, 10, "w", 5600.0)                        # the entry cannot belong to this launch
     assert rec["frac"] is None and rec["achieved"] is None and rec["traffic_entry_inconsistent_with_this_run"]
-    assert rec["frac_upper_bound"] <= 1.0
+    assert rec["frac_bound_without_counters"] <= 1.0
+
+
+def test_no_field_of_the_record_contradicts_another(traffic_table):
+    """round 4's line carried frac 0.885 beside frac_upper_bound 0.854.  The fabric-level fraction is labelled
+    as such, the DRAM-level bounds sit on either side of what DRAM can have moved and never above the fabric figure, and a bound
+    'without counters' is printed only when there are none."""
+    n, nnz, C = 80_000_000, 1_000_000_000, 128
+    b_alg, b_min = bench.alg_bytes_per_iteration(n, nnz, C), bench.min_bytes_per_iteration(n, nnz, C)
+    traffic_table["w"] = 543.9e9                                                                   # round 4's in-run counter figure
+    monkey_read = bench.MEASURED_READ_PEAK[0]                                                      # 7000 GB/s (fixture)
+    rec = bench.roofline_record(n, nnz, C, 0.07685, 10, "w", 5565.0)
+    assert rec["frac"] == pytest.approx(543.9e9 / 0.07685 / 1e9 / 8000.0) and "fabric" in rec["frac_level"] and "NOT DRAM" in rec["frac_level"]
+    assert rec["frac_bound_without_counters"] is None
+    assert rec["dram_frac_lower_bound"] == pytest.approx(b_min / 0.07685 / 1e9 / 8000.0) == rec["frac_compulsory"]
+    assert rec["dram_frac_upper_bound"] == pytest.approx(min(rec["frac"], monkey_read / 8000.0))
+    assert rec["dram_frac_lower_bound"] <= rec["dram_frac_upper_bound"] <= rec["frac"] <= 1.0
+    assert rec["fabric_rate_over_read_stream"] == pytest.approx(rec["achieved"] / monkey_read)    # may exceed 1: named as a ratio, not a fraction
+    assert not [k for k in rec if k.startswith("frac_of_measured")]
+    # the in-run no-reuse yardstick beside it
+    assert rec["no_reuse_gather_GBs"] is None and rec["frac_of_gather_ceiling"] is None
+    bench.add_gather_ceiling(rec, {"GBs": 5800.0, "launch_ms": 130.0, "entries": 1_279_999_000})
+    assert rec["no_reuse_gather_frac"] == pytest.approx(0.725) and rec["frac_of_gather_ceiling"] == pytest.approx(rec["achieved"] / 5800.0)
+    assert bench.add_gather_ceiling(dict(rec), None)["no_reuse_gather_GBs"] == 5800.0               # no yardstick: nothing changes
+    json.dumps(rec)
+
+
+def test_flat_keys_carry_what_recomputing_the_fraction_needs(traffic_table):
+    """the driver keeps flat scalars of ``roofline`` and drops ``secondary``; config 4 and the narrow widths ride
+    in the primary object as <prefix>_* keys from which frac = min(alg, traffic) / (launch_ms) / peak can be recomputed."""
+    n, nnz, C = 10_000_000, 100_000_000, 256
+    traffic_table["c4"] = 106.7e9
+    rec = bench.roofline_record(n, nnz, C, 0.01430, 10, "c4", 5600.0)
+    flat = bench.flat_keys("config4", rec, ms_per_step=143.0, edges_per_s=7.0e9)
+    for key in ("config4_ms_per_step", "config4_launch_ms", "config4_frac", "config4_traffic", "config4_alg_bytes_per_launch",
+                "config4_min_bytes_per_launch", "config4_frac_compulsory", "config4_traffic_in_run", "config4_edges_per_s"):
+        assert key in flat and not isinstance(flat[key], (dict, list)), key
+    again = min(flat["config4_alg_bytes_per_launch"], flat["config4_traffic"]) / (flat["config4_launch_ms"] * 1e-3) / 1e9 / 8000.0
+    assert again == pytest.approx(flat["config4_frac"]) and flat["config4_frac"] > 0.9
+    assert "config4_no_reuse_gather_frac" not in flat                                               # absent values are left out, not null
+    narrow = bench.flat_keys("config4_graph_C7", bench.roofline_record(n, nnz, 7, 0.0016, 10, "nothing", 5600.0), ms_per_step=16.0)
+    assert "config4_graph_C7_frac" not in narrow and narrow["config4_graph_C7_ms_per_step"] == 16.0   # no counters, no fraction
+    assert [C for C in bench.SEGMENT_WIDTHS] == [256, 128, 64, 40, 8, 7]                             # 40 and 7: the widths gnntf's APPNP propagates (filter.py:33-35)
+
+
+def test_segments_of_a_marked_counter_run(tmp_path):
+    """The config-4-graph pass (`bench.py --pmc-child segments`): a marker kernel cuts ONE process into segments; measured piece i
+    is segment 2 i + 1 (a warm-up of its own precedes each), bytes = FETCH x 2 KiB + WRITE KiB over the SpMM kernels only."""
+    head = "Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+    seq = [("k_build", 9), ("k_stream<8, false>", 0),                                                # segment 0 | marker -> 1
+           ("k_spmm_wave<4, 8, 8>", 100), ("k_spmm_long_partial<4>", 10), ("at::fill", 77), ("k_stream<8, false>", 0),   # segment 1 (measured piece 0)
+           ("k_spmm_group<4, 32, 4, false>", 55), ("k_stream<8, false>", 0),                         # segment 2 (warm-up of piece 1)
+           ("k_spmm_group<4, 32, 4, false>", 50), ("k_gather_rows32", 5), ("k_stream<8, false>", 0)]  # segment 3 (measured piece 1)
+
+    def csv_of(counter, scale):
+        return head + "".join(f'{d + 1},"{k}",{counter},{v * scale}\n' for d, (k, v) in enumerate(seq))
+    (tmp_path / "f.csv").write_text(csv_of("FETCH_SIZE", 1.0))
+    (tmp_path / "w.csv").write_text(csv_of("WRITE_SIZE", 0.1))
+    seg = bench.fabric_bytes_by_segment(str(tmp_path / "f.csv"), str(tmp_path / "w.csv"))
+    assert seg[1] == pytest.approx(110 * 2048 + 11 * 1024) and seg[3] == pytest.approx(50 * 2048 + 5 * 1024)
+    assert seg[2] == pytest.approx(55 * 2048 + 5.5 * 1024) and 0 not in seg
+    plan = bench.segment_plan(10)
+    assert [p[0] for p in plan[:2]] == ["rmat_n10000000_nnz100000000_C256", "rmat_n10000000_nnz100000000_C128"] and plan[0][1] == 10
+    assert plan[-2] == ("train_forward_rmat_n10000000_nnz100000000_C64", bench.TRAIN_LAUNCHES) and plan[-1][0].startswith("train_backward_")
+
+
+def test_training_iteration_compulsory_bytes():
+    n, nnz, C = 1000, 20000, 64
+    assert bench.min_bytes_dropped_iteration(n, nnz, C) == 8 * nnz + 12 * n + 12 * n * C
+    assert bench.min_bytes_dropped_iteration(n, nnz, C, backward=True) == 8 * nnz + 12 * n + 16 * n * C
+    assert bench.min_bytes_dropped_iteration(n, nnz, C) <= bench.alg_bytes_dropped_iteration(n, nnz, nnz // 2, C)
 
 
 def test_training_iteration_byte_model():

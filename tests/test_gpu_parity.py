@@ -748,20 +748,27 @@ def test_fused_ppr_loop_equals_layers(gnntf):
         ev = model.layers()[-1](model, H0.detach())
     adj = model.get_adjacency(0.5)
     assert torch.equal(ev, gnntf.appnp_propagate(adj, H0.detach(), 0.1, 10))
-    # what a user gets without asking: the loop layer whenever filter.py's defaults are in force, the K layers otherwise
+    # what a user gets without asking: filter.py:30-35's own list (K PPRIteration layers), executed as one fused run
     default = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7)
-    assert isinstance(default.layers()[-1], gnntf.PPRLoop) and not any(isinstance(l, gnntf.PPRIteration) for l in default.layers())
+    assert sum(isinstance(l, gnntf.PPRIteration) for l in default.layers()) == 10 and not any(isinstance(l, gnntf.PPRLoop) for l in default.layers())
     by_layer = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, activation=gnntf.relu)
     assert sum(isinstance(l, gnntf.PPRIteration) for l in by_layer.layers()) == 10
     with pytest.raises(Exception, match="identity activation"):
         gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, activation=gnntf.relu, fused=True)
-    # predict() through the default model == the layer-by-layer model with the same weights (eval mode), bit for bit
-    ref = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, fused=False)
-    for v, w in zip(default.vars(), ref.vars()):
+    # predict() through the default model == the strictly layer-by-layer execution of the same list == the collapsed model with the
+    # same weights (eval mode), bit for bit; the fused run is ONE library call (the kernel log says so), layer by layer is K
+    collapsed = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, fused=True)
+    for v, w in zip(default.vars(), collapsed.vars()):
         w.assign(v.identity())
-    default.training_mode(False); ref.training_mode(False)
+    default.training_mode(False); collapsed.training_mode(False)
     with torch.no_grad():
-        assert torch.equal(default(default.features), ref(ref.features))
+        as_run = default(default.features)
+        inner = [l.value for l in default.layers()[-10:]]                       # lazy per-iteration values, computed on demand
+        default.fuse_runs = False
+        by_layers = default(default.features)
+        assert torch.equal(as_run, by_layers) and torch.equal(as_run, collapsed(collapsed.features))
+        for lazy, layer in zip(inner, default.layers()[-10:]):
+            assert torch.equal(lazy, layer.value)
 
 
 @pytest.mark.parametrize("C", [7, 64, 256])
@@ -913,21 +920,30 @@ def test_hand_built_ppr_iteration_stack_runs_fused(gnntf):
     assert torch.equal(got, want)
 
 
-def test_appnp_layer_list_matches_the_reference_when_not_fused(gnntf):
-    """filter.py:30-35: Dropout, one Dense per latent width, the output Dense, then ``iterations`` PPRIteration layers.
-    ``fused=False`` reproduces exactly that list (the default collapses the iterations into one PPRLoop layer -- a structural
-    difference stated in README / INTEGRATION; results are the same)."""
+def test_appnp_layer_list_matches_the_reference_by_default(gnntf):
+    """filter.py:30-35: Dropout, one Dense per latent width, the output Dense, then ``iterations`` PPRIteration layers -- what
+    ``APPNP(...)`` builds without being asked (the container fuses the run at execution); ``fused=True`` is the explicit opt-in
+    to the collapsed list."""
     import networkx as nx
     G = nx.path_graph(6)
     X = np.eye(6, dtype=np.float32)
-    model = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, latent_dims=[8, 4], iterations=10, fused=False)
+    model = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, latent_dims=[8, 4], iterations=10)
     names = [type(l).__name__ for l in model.layers()]
     assert names == ["Dropout", "Dense", "Dense", "Dense"] + ["PPRIteration"] * 10
     its = model.layers()[4:]
     assert all(l.H0 is model.layers()[3] and l.restart_probability == 0.1 and l.graph_dropout == 0.5 for l in its)
-    default = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, latent_dims=[8, 4], iterations=10)
-    assert [type(l).__name__ for l in default.layers()] == ["Dropout", "Dense", "Dense", "Dense", "PPRLoop"]
-    assert default.layers()[-1].iterations == 10 and default.layers()[-1].H0 is default.layers()[3]
+    assert len(gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3).layers()) == 13           # the reference's defaults: 1 + 1 + 1 + 10
+    collapsed = gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, latent_dims=[8, 4], iterations=10, fused=True)
+    assert [type(l).__name__ for l in collapsed.layers()] == ["Dropout", "Dense", "Dense", "Dense", "PPRLoop"]
+    assert collapsed.layers()[-1].iterations == 10 and collapsed.layers()[-1].H0 is collapsed.layers()[3]
+    # a trainable restart probability (a=None) raises where the reference raises: create_var() without a shape (filter.py:35)
+    with pytest.raises(Exception):
+        gnntf.APPNP(gnntf.graph2adj(G), X, num_classes=3, a=None)
+    # run(h, first=i): the container's loop continued from a value the caller holds
+    model.reset(); model.training_mode(False)
+    with torch.no_grad():
+        whole = model(model.features)
+        assert torch.equal(model.run(model.layers()[3].value, first=4), whole)
 
 
 def test_train_and_predict_end_to_end(gnntf):
