@@ -482,13 +482,20 @@ def split_columns(C, chunks):
     return [(cuts[k], cuts[k + 1]) for k in range(chunks) if cuts[k + 1] > cuts[k]]
 
 
-def cover_push_mask(row, col, owner, rank, n_local, bnd):
-    """Which cross entries are PUSHED (summed by the column's owner) instead of pulled: a greedy vertex cover of
-    the cross entries between this block and each peer.  An entry (i, j), j owned by q, is first given to the
-    endpoint that covers more entries of that block pair (the column j if at least as many of this block's rows
-    reference it as row i has columns on q, else the row i); then every entry of a row that is pushed anyway
-    joins the push (free), which also frees the columns only such rows referenced.  A peer whose cover does not
-    come out smaller than its plain halo keeps the plain halo.
+def cover_push_mask(row, col, owner, rank, n_local, bnd, push_weight=0.0):
+    """Which cross entries are PUSHED (summed by the column's owner) instead of pulled: a greedy WEIGHTED vertex cover of
+    the cross entries between this block and each peer.  Choosing a column j (pull) costs one row on the link and one gather
+    on the sender: weight 1 + w; choosing a row i (push) costs one row on the link and its d_i entries on that peer in the
+    SENDER's push SpMM -- work that must finish before the row can leave: weight 1 + w d_i (w = ``push_weight``).  An entry
+    (i, j) is first given to the endpoint with the lower weight per entry it covers: the column when
+    d_i (1 + w) <= c_j (1 + w d_i), c_j = rows of this block referencing j.  w = 0 is the plain minimum-rows cover (the column
+    if at least as many rows reference it as row i has columns on q); as w grows the plan approaches the pull-only halo (in the
+    limit only rows whose columns nobody else references stay pushed: fewer rows on the link for the same work); in between it
+    trades rows on the link for partial sums that delay them (the table over w).  Then every entry of a row
+    that is pushed anyway joins the push (no further row on the link), which also frees the columns only such rows
+    referenced.  A peer whose cover does not come out smaller than its plain halo keeps the plain halo.  ANY mask is a valid
+    plan (every cross entry is multiplied exactly once, by one side): the weight changes cost, never results beyond float32
+    summation order.
     ``row`` local ids, ``col`` global ids, ``owner`` rank owning each column (all int64 [m]); ``bnd`` the upper
     bounds of the P blocks.  Returns bool [m]."""
     world, n_global = int(bnd.numel()), int(bnd[-1])
@@ -501,7 +508,12 @@ def cover_push_mask(row, col, owner, rank, n_local, bnd):
     kr = eq * n_local + er                                           # (peer, row) key
     dr = torch.bincount(kr, minlength=world * n_local)               # entries of row i on peer q
     dc = torch.bincount(ec, minlength=n_global)                      # rows of this block referencing column j
-    col_wins = dc[ec] >= dr[kr]
+    if push_weight and push_weight > 0:
+        w, d_row, c_col = float(push_weight), dr[kr].to(torch.float64), dc[ec].to(torch.float64)
+        col_wins = d_row * (1.0 + w) <= c_col * (1.0 + w * d_row)
+        del d_row, c_col
+    else:
+        col_wins = dc[ec] >= dr[kr]
     halo_per_peer = torch.bincount(torch.bucketize(torch.nonzero(dc).reshape(-1), bnd, right=True), minlength=world)
     del dr, dc
     pulled_col = torch.zeros(n_global, dtype=torch.bool, device=dev)
@@ -571,11 +583,13 @@ class ShardedGraph:
 
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
                  relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False, early_pull=False,
-                 tune_overlap=True):
+                 tune_overlap=True, push_weight=0.0):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
         (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.  Collective: every rank of the
         vertex partition (``comm`` / ``group``) must call it with the same options.
         ``cover``: "cover" (pull/push vertex cover, default) or "pull" (classic halo; bitwise the one-GPU sums).
+        ``push_weight`` (cover plans): what a pushed row's entries on the sender weigh against a row on the link
+        (cover_push_mask; 0 = fewest rows on the link, larger = fewer and shorter partial sums, more pulled rows).
         ``split_rows``: interior rows (no remote column) as a handle of their own, computed before the halo is
         waited for -- when they hold at least MIN_INTERIOR_SHARE of the block's entries ("always": whatever they hold).  ``chunks``: independent column chunks whose exchange and SpMM overlap (default 2).
         ``keep_entries``: keep (global row, global col, normalised value, pushed?) of this rank's entries in
@@ -609,6 +623,9 @@ class ShardedGraph:
         N = self.bounds[-1]
         self.lo, self.hi, self.n_global, self.n_local = lo, hi, N, hi - lo
         self.cover, self.chunks, self.early_pull = cover, max(1, int(chunks)), bool(early_pull)
+        self.push_weight = float(push_weight) if cover == "cover" else 0.0
+        if self.push_weight < 0:
+            raise Exception("ShardedGraph: push_weight must not be negative")
         self.n_send_pull_max = self.n_send_push_max = 0
         if idx_global.numel() and (int(idx_global[:, 0].min()) < lo or int(idx_global[:, 0].max()) >= hi):
             raise Exception("ShardedGraph: an entry's row is outside this rank's range [%d, %d)" % (lo, hi))
@@ -678,7 +695,7 @@ class ShardedGraph:
         self.send_graph = self.push_graph = self.halo = None
         self.empty_rows_unreferenced = False
         self.stats = dict(pull_rows=0, push_rows=0, pull_only_rows=0, send_rows=0, interior_rows=self.n_local,
-                          boundary_rows=0, local_rows=self.n_local)
+                          boundary_rows=0, local_rows=self.n_local, busiest_link_rows=0, push_entries=0)
 
     # ---- a block among several: halo plan --------------------------------------------------------------
     def _build_block(self, row, col, nvals, split_rows):
@@ -687,7 +704,7 @@ class ShardedGraph:
         bnd = torch.tensor(self.bounds[1:], dtype=torch.int64, device=dev)
         owner = torch.bucketize(col, bnd, right=True)
         remote = owner != me
-        push = cover_push_mask(row, col, owner, me, n_local, bnd) if self.cover == "cover" else torch.zeros_like(remote)
+        push = cover_push_mask(row, col, owner, me, n_local, bnd, self.push_weight) if self.cover == "cover" else torch.zeros_like(remote)
         pull = remote & ~push
         if self.entries is not None:
             self.entries[3] = push.clone()
@@ -833,7 +850,10 @@ class ShardedGraph:
             self.col_gid = gid
             be.set_block(self.graph, lo, n_before, gid)
         self.stats = dict(pull_rows=sum(self.pull_counts), push_rows=sum(self.push_counts), pull_only_rows=n_pull_only,
-                          send_rows=self.n_send, interior_rows=n_local - n_bnd, boundary_rows=n_bnd, local_rows=n_local)
+                          send_rows=self.n_send, interior_rows=n_local - n_bnd, boundary_rows=n_bnd, local_rows=n_local,
+                          # every pair of ranks has its own link: what an exchange lasts is the BUSIEST one, either direction
+                          busiest_link_rows=max(self.recv_counts + self.send_counts),
+                          push_entries=(self.push_graph.nnz if self.push_graph is not None else 0))
         t = torch.tensor([self.n_send_pull, self.n_send - self.n_send_pull], dtype=torch.int64, device=dev)
         comm.all_reduce(t, dist.ReduceOp.MAX)
         self.n_send_pull_max, self.n_send_push_max = int(t[0]), int(t[1])
@@ -1181,7 +1201,8 @@ class ShardedGraph:
 
     def halo_stats(self):
         """Max over ranks of the plan sizes (rows): what crosses the links per iteration and how the rows split."""
-        keys = ["pull_rows", "push_rows", "pull_only_rows", "send_rows", "interior_rows", "boundary_rows", "local_rows"]
+        keys = ["pull_rows", "push_rows", "pull_only_rows", "send_rows", "interior_rows", "boundary_rows", "local_rows", "busiest_link_rows",
+                "push_entries"]
         t = torch.tensor([self.stats[k] for k in keys], dtype=torch.int64, device=self.device)
         self.comm.all_reduce(t, dist.ReduceOp.MAX)
         out = {"max_" + k: int(v) for k, v in zip(keys, t.tolist())}
@@ -1189,6 +1210,7 @@ class ShardedGraph:
         self.comm.all_reduce(t, dist.ReduceOp.MAX)
         out["max_halo_rows"] = int(t.item())
         out["cover"], out["split_rows"], out["chunks"] = self.cover, bool(getattr(self, "split_rows", False)), self.chunks
+        out["push_weight"] = self.push_weight
         out["early_pull"] = self.early_pull
         return out
 

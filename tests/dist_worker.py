@@ -446,7 +446,9 @@ def main():
                                  mode == "dropout_directed")
     on_gpu = len(sys.argv) > 2 and sys.argv[2] == "cuda"          # GPU box: every rank shares cuda:0, libgnx.so backend
     opts = (sys.argv[3] if len(sys.argv) > 3 else "cover,split,2").split(",")
-    options = dict(cover=opts[0], split_rows="always" if opts[1] == "split" else False, chunks=int(opts[2]), keep_entries=True)
+    options = dict(cover=opts[0].split("@")[0], split_rows="always" if opts[1] == "split" else False, chunks=int(opts[2]), keep_entries=True)
+    if "@" in opts[0]:                                             # "cover@0.25": the weighted cover (cover_push_mask's push_weight)
+        options["push_weight"] = float(opts[0].split("@")[1])
     dev = torch.device("cuda:0" if on_gpu else "cpu")
     backend = None if on_gpu else OracleBackend()
     C, K, a = (64 if on_gpu else 12), 10, 0.1

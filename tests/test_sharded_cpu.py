@@ -26,10 +26,48 @@ def launch(world, mode, device="cpu", options="cover,split,2"):
     assert "OK " + mode in res.stdout
 
 
-@pytest.mark.parametrize("world,options", [(2, "cover,split,2"), (3, "cover,split,2"), (2, "pull,whole,1"), (3, "pull,split,3")])
+@pytest.mark.parametrize("world,options", [(2, "cover,split,2"), (3, "cover,split,2"), (2, "pull,whole,1"), (3, "pull,split,3"),
+                                           (2, "cover@0.25,split,2"), (3, "cover@3,whole,2")])
 def test_sharded_matches_single_process_oracle(world, options):
-    """Fixed graph with duplicates, uneven blocks: cover and pull-only plans, split and whole rows, 1-3 chunks."""
+    """Fixed graph with duplicates, uneven blocks: cover (plain and weighted: "cover@w") and pull-only plans, split and whole
+    rows, 1-3 chunks."""
     launch(world, "slices", options=options)
+
+
+def test_weighted_cover_runs_from_the_minimum_cover_to_the_plain_halo():
+    """cover_push_mask(push_weight=w): w = 0 is the minimum-rows cover; growing w sums fewer entries on the sender's side for more
+    rows on the link, towards the pull-only halo (in the limit only rows whose columns no other row references stay pushed:
+    one row on the link instead of several, for the same work).  Any mask is a valid plan: every cross entry is either pushed
+    or its column pulled, local entries are never pushed."""
+    import numpy as np
+    import torch
+    from gnntf import sharded
+    import graphs
+    n, world, rank = 4000, 4, 1
+    coo, _, _ = graphs.rmat_symmetric_coo(n, 60000, seed=9)
+    bounds = sharded.uniform_bounds(n, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = np.unique(coo[(coo[:, 0] >= lo) & (coo[:, 0] < hi)], axis=0)
+    row, col = torch.from_numpy(mine[:, 0] - lo), torch.from_numpy(mine[:, 1])
+    bnd = torch.tensor(bounds[1:], dtype=torch.int64)
+    owner = torch.bucketize(col, bnd, right=True)
+    remote = owner != rank
+
+    def plan(w):
+        push = sharded.cover_push_mask(row, col, owner, rank, hi - lo, bnd, w)
+        assert not bool(push[~remote].any())
+        pulled_cols = int(torch.unique(col[remote & ~push]).numel())
+        pushed_rows = int(torch.unique(owner[push] * n + row[push]).numel())
+        return int(push.sum()), pulled_cols + pushed_rows
+    halo = int(torch.unique(col[remote]).numel())
+    table = [plan(w) for w in (0.0, 0.05, 0.3, 2.0, 1e9)]
+    assert table[0] == plan(0) and table[0][1] < 0.8 * halo                  # the plain cover: well below the halo on a power-law graph
+    assert table[-1][0] < 0.7 * table[0][0] and table[-1][1] > table[0][1]    # w -> infinity: the push shrinks, part of the halo is back
+    pushed = [t[0] for t in table]
+    rows = [t[1] for t in table]
+    assert all(a >= b for a, b in zip(pushed, pushed[1:])) and pushed[1] < pushed[0]      # fewer entries summed on the sender ...
+    assert all(a <= b for a, b in zip(rows, rows[1:]))                                    # ... for more rows on the link
+    assert all(r <= halo for r in rows)                                                   # never more than the plain halo
 
 
 @pytest.mark.parametrize("world,options", [(2, "cover,split,2"), (3, "cover,whole,2")])

@@ -58,7 +58,41 @@ def bfs_positions(src, dst, n, start):
     return pos, levels
 
 
-def tail_key(name, u, v, n, deg):
+def community_pairs(n, m, seed, device, mix=0.2, gamma=2.5, tau=2.0, size_lo=64, size_hi=65536, max_weight=30000.0):
+    """A community-structured power-law graph (BTER / LFR-like, what citation and co-purchase graphs such as Cora or ogbn-arxiv look
+    like and R-MAT does not): planted communities with power-law SIZES (exponent ``tau``, ``size_lo`` ... ``size_hi`` vertices) x
+    power-law expected DEGREES (Pareto weights, exponent ``gamma``).  Each of the ``m`` undirected pairs picks its source in
+    proportion to the weights and its target, with probability 1 - ``mix``, inside the source's community (again in proportion
+    to the weights), else anywhere.  Vertices are then relabelled by a random permutation, like the bench graph.
+    Returns (u, v, community of every vertex under the FINAL labels)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    draws = max(1024, int(4 * n / size_lo))
+    sizes = (size_lo * (1.0 - torch.rand(draws, device=device, generator=gen, dtype=torch.float64)).pow(-1.0 / (tau - 1.0))).clamp(max=size_hi).long()
+    ends = torch.cumsum(sizes, 0)
+    ends = ends[: int(torch.searchsorted(ends, torch.tensor([n], device=device))[0]) + 1].clamp(max=n)          # community c = [ends[c-1], ends[c])
+    comm = torch.bucketize(torch.arange(n, device=device), ends, right=True)
+    weight = (1.0 - torch.rand(n, device=device, generator=gen, dtype=torch.float64)).pow(-1.0 / (gamma - 1.0)).clamp(max=max_weight)
+    cdf = torch.cumsum(weight, 0)
+    total = float(cdf[-1])
+    u = torch.searchsorted(cdf, torch.rand(m, device=device, generator=gen, dtype=torch.float64) * total).clamp(max=n - 1)
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), ends[:-1]])
+    c_lo = torch.where(starts > 0, cdf[(starts - 1).clamp(min=0)], torch.zeros_like(cdf[:1]))                    # weight mass before each community
+    c_hi = cdf[ends - 1]
+    cu = comm[u]
+    inside = torch.rand(m, device=device, generator=gen) >= mix
+    lo = torch.where(inside, c_lo[cu], torch.zeros_like(c_lo[:1]))
+    hi = torch.where(inside, c_hi[cu], torch.full_like(c_hi[:1], total))
+    v = torch.searchsorted(cdf, lo + torch.rand(m, device=device, generator=gen, dtype=torch.float64) * (hi - lo)).clamp(max=n - 1)
+    del cdf, weight, lo, hi, inside, cu
+    keep = u != v
+    u, v = u[keep], v[keep]
+    perm = torch.randperm(n, device=device, generator=gen)
+    comm_final = torch.empty_like(comm)
+    comm_final[perm] = comm
+    return perm[u], perm[v], comm_final
+
+
+def tail_key(name, u, v, n, deg, comm=None):
     """int64 [n]: the secondary sort key inside a degree bin."""
     dev = u.device
     if name in ("workload", "degree"):
@@ -71,6 +105,8 @@ def tail_key(name, u, v, n, deg):
         key = torch.full((n,), INF, dtype=torch.int64, device=dev)
         key.scatter_reduce_(0, dst, rank[src], reduce="amin")            # rank of the most popular neighbour
         return key, {}
+    if name == "planted":                                                # the generator's own communities: the best any locality order can do
+        return comm.clone(), {}
     if name == "bfs":
         pos, levels = bfs_positions(src, dst, n, int(order[0]))
         return pos, {"bfs_levels": levels, "bfs_reached": int((pos < INF).sum())}
@@ -84,21 +120,29 @@ def main():
     ap.add_argument("--feats", type=str, default="8,16,32")
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--graph", choices=["rmat", "community"], default="rmat",
+                    help="rmat: the bench graph (config 4); community: planted partition x power-law degrees (community_pairs), same N / entries")
+    ap.add_argument("--mix", type=float, default=0.2, help="community graph: share of the pairs that leave their community")
+    ap.add_argument("--pure", action="store_true", help="order by the tail key ALONE (no degree bins in front of it) -- for C > 16, where the library does not relabel")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     gnntf.set_default_device(dev)
     n, K = a.nodes, 10
-    u, v = sharded.rmat_relabelled_pairs(n, a.entries // 2, seed=1, device=dev)
+    comm = None
+    if a.graph == "community":
+        u, v, comm = community_pairs(n, a.entries // 2, 1, dev, mix=a.mix)
+    else:
+        u, v = sharded.rmat_relabelled_pairs(n, a.entries // 2, seed=1, device=dev)
     deg = torch.bincount(u, minlength=n) + torch.bincount(v, minlength=n)
     lib = nat.lib()
-    names = [x for x in (a.only.split(",") if a.only else ["workload", "degree", "hub_grouped", "bfs"])]
+    names = [x for x in (a.only.split(",") if a.only else ["workload", "degree", "hub_grouped", "bfs"] + (["planted"] if comm is not None else []))]
     for name in names:
         torch.cuda.synchronize(); t0 = time.time()
-        key, info = tail_key(name, u, v, n, deg)
+        key, info = tail_key(name, u, v, n, deg, comm)
         if name == "workload":
             newid = None
         else:
-            bin_ = 512 - deg.clamp(max=512)                               # the library's degree bins (heaviest first)
+            bin_ = torch.zeros_like(deg) if a.pure else 512 - deg.clamp(max=512)      # the library's degree bins (heaviest first)
             k1 = torch.argsort(key, stable=True)                          # lexicographic (bin, key, old id) by two stable sorts
             order = k1[torch.argsort(bin_[k1], stable=True)]
             newid = torch.empty_like(order)
@@ -125,7 +169,8 @@ def main():
                     times.append(s.elapsed_time(e))
             ms = sorted(times)[len(times) // 2]
             b = bench.alg_bytes_per_iteration(n, g.nnz, C)
-            print(json.dumps(dict(order=name, C=C, ms_per_K10=ms, kernel=g.last_kernel(), alg_frac_of_8TBs=b * K / ms / 1e6 / 8000,
+            print(json.dumps(dict(graph=a.graph, entries=g.nnz, empty_rows=int((deg == 0).sum()), max_degree=int(deg.max()), pure=a.pure,
+                                  order=name, C=C, ms_per_K10=ms, kernel=g.last_kernel(), alg_frac_of_8TBs=b * K / ms / 1e6 / 8000, alg_GB_per_launch=b / 1e9,
                                   order_seconds=round(t_order, 2), checksum=float(out.double().sum()), **info)), flush=True)
             del H0, out, work
         del g, adj

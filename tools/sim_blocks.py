@@ -111,7 +111,7 @@ class LoopbackComm(sharded.Comm):
             t_row = cols_g[sel] - lo_q                                  # q's local row (my column j)
             t_col = rows_g[sel]                                         # global id of my row i: q's remote column
             t_own = torch.full_like(t_col, me)
-            push = sharded.cover_push_mask(t_row, t_col, t_own, q, n_q, bnd) if sg.cover == "cover" else torch.zeros_like(sel[sel])
+            push = sharded.cover_push_mask(t_row, t_col, t_own, q, n_q, bnd, sg.push_weight) if sg.cover == "cover" else torch.zeros_like(sel[sel])
             asked = torch.unique(t_col[~push])                          # q pulls these rows of mine
             keys = torch.unique(t_row[push])                            # q's pushed rows for peer me, ascending = slot order
             slot = torch.searchsorted(keys, t_row[push]) if keys.numel() else torch.zeros(0, dtype=torch.int64, device=dev)
@@ -127,6 +127,57 @@ class SimGraph(sharded.ShardedGraph):
         return super()._build_block(row, col, nvals, split_rows)
 
 
+def spin_rate():
+    """Cycles of torch.cuda._sleep per second on this card (the emulated link's clock)."""
+    torch.cuda._sleep(1000); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
+    return 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+
+
+def sweep(a, idx, vals, bounds, degrees, dev):
+    """The table of DESIGN section 5: one plan per entry of --sweep (a push weight of the weighted cover, or 'pull') on the same
+    graph: what the plan puts on the busiest link, what it leaves to the sender's push SpMM, the block's kernels alone, and the
+    K = 10 step with the exchange replaced by emulated link time at every rate of --sweep-rates (2 chunks, early pull)."""
+    P, r, C = a.world, a.rank, a.feats
+    rates = [float(x) for x in a.sweep_rates.split(",") if x]
+    spin = spin_rate() if rates else None
+    _skipped = [torch.cuda.Stream(dev) for _ in range(max(a.lane_skip, 1))]
+    for plan in a.sweep.split(","):
+        cover, weight = ("pull", 0.0) if plan == "pull" else ("cover", float(plan))
+        t0 = time.time()
+        comm = LoopbackComm(P, r, degrees, "copy")
+        sg = SimGraph(idx, vals, bounds, comm=comm, cover=cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True, push_weight=weight)
+        sg.entries = None
+        comm.mirrored = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        t_plan = time.time() - t0
+        H0 = torch.rand(sg.n_local, C, device=dev) * 2 - 1
+        state = sg.make_state(H0)
+        t_c = sg.time_compute(state, 0.1)
+        st = sg.stats
+        rec = {"world": P, "plan": plan, "cover": cover, "push_weight": weight, "chunks": a.chunks, "plan_s": round(t_plan, 1),
+               "pull_rows": st["pull_rows"], "push_rows": st["push_rows"], "halo_rows": st["pull_rows"] + st["push_rows"],
+               "busiest_link_rows": st["busiest_link_rows"], "busiest_link_MB_per_iteration": st["busiest_link_rows"] * C * 4 / 1e6,
+               "halo_GB_per_iteration": (st["pull_rows"] + st["push_rows"]) * C * 4 / 1e9, "push_entries": st["push_entries"],
+               "local_entries": sg.nnz_local, "kernels_ms_per_iteration": t_c * 1e3, "step_over_10_ms": {}}
+        for rate in rates:
+            comm.transport, comm.link_GBs, comm.spin_per_s = f"sleep:{rate}", rate, spin
+            for early in (False, True):
+                sg.propagate(state, 0.1, 10, early_pull=early)
+                torch.cuda.synchronize()
+                t0 = time.time()
+                for _ in range(3):
+                    sg.propagate(state, 0.1, 10, early_pull=early)
+                torch.cuda.synchronize()
+                rec["step_over_10_ms"][f"{rate:g}_GBs" + ("_early_pull" if early else "")] = round((time.time() - t0) / 3 / 10 * 1e3, 3)
+            rec.setdefault("exchange_ms_per_iteration", {})[f"{rate:g}_GBs"] = round(st["busiest_link_rows"] * C * 4 / (rate * 1e9) * 1e3, 3)
+        print(json.dumps(rec), flush=True)
+        del sg, state, H0, comm
+        torch.cuda.empty_cache()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
@@ -135,6 +186,12 @@ def main():
     ap.add_argument("--entries", type=int, default=1_000_000_000)
     ap.add_argument("--feats", type=int, default=128)
     ap.add_argument("--cover", default="cover")
+    ap.add_argument("--push-weight", type=float, default=0.0, help="cover plans: weight of a pushed row's sender-side entries (cover_push_mask)")
+    ap.add_argument("--sweep", default="",
+                    help="comma list of plans -- a push weight, or 'pull' -- rehearsed one after the other on the SAME generated graph; with "
+                         "--sweep-rates (GB/s per link and direction) every plan is also stepped under emulated link time.  Prints one JSON "
+                         "line per plan: rows on the busiest link, entries in the push SpMM, kernels per iteration, step / 10 per rate")
+    ap.add_argument("--sweep-rates", default="35,42,50,64")
     ap.add_argument("--chunks", type=int, default=2)
     ap.add_argument("--whole-rows", action="store_true")
     ap.add_argument("--early-pull", action="store_true")
@@ -167,16 +224,16 @@ def main():
     vals = torch.ones(idx.shape[0], dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
+    if a.sweep:
+        return sweep(a, idx, vals, bounds, degrees, dev)
     t0 = time.time()
     comm = LoopbackComm(P, r, degrees, a.transport)
     if a.transport.startswith("sleep"):
         comm.link_GBs = float(a.transport.split(":")[1])
-        torch.cuda._sleep(1000); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); torch.cuda._sleep(20_000_000); e1.record(); torch.cuda.synchronize()
-        comm.spin_per_s = 20_000_000 / (e0.elapsed_time(e1) * 1e-3)
+        comm.spin_per_s = spin_rate()
     _skipped = [torch.cuda.Stream(dev) for _ in range(a.lane_skip)]
-    sg = SimGraph(idx, vals, bounds, comm=comm, cover=a.cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True)
+    sg = SimGraph(idx, vals, bounds, comm=comm, cover=a.cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True,
+                  push_weight=a.push_weight)
     sg.entries = None
     del idx, vals, comm.mirrored
     torch.cuda.synchronize()
