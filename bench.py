@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd")]
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PUSH_WEIGHTS_DEFAULT = ""           # weighted covers the N > 1 selection times beside "cover" and "pull" (the table over w)
 WORKLOADS = {"config5": (80_000_000, 1_000_000_000, 128),       # BASELINE.json configs[4]: the scaling graph (default)
              "config4": (10_000_000, 100_000_000, 256)}          # BASELINE.json configs[3]: the roofline run
 
@@ -41,8 +42,12 @@ def parse():
     ap.add_argument("--iterations", type=int, default=10)
     ap.add_argument("--alpha", type=float, default=0.1)
     ap.add_argument("--grid", type=str, default="", help="PVxPF process grid (vertex blocks x feature slices); default Nx1")
-    ap.add_argument("--cover", choices=["auto", "cover", "pull"], default="auto",
-                    help="halo plan: pull/push vertex cover, plain pull, or auto = one step of each is timed before the run and the faster one kept")
+    ap.add_argument("--cover", default="auto",
+                    help="halo plan: cover (pull/push vertex cover), cover@W (weighted cover, push weight W), pull (plain halo), or auto = one step "
+                         "of each is timed before the run and the fastest kept")
+    ap.add_argument("--push-weights", type=str, default=PUSH_WEIGHTS_DEFAULT,
+                    help="--cover auto: weighted covers timed beside the plain one (cover_push_mask's push_weight: fewer entries summed on the sender's "
+                         "side for more rows on the link), comma separated; empty = none")
     ap.add_argument("--chunks", type=int, default=0, help="column chunks whose exchange and SpMM overlap (0 = auto: 1, 2 and 4 are tried)")
     ap.add_argument("--early-pull", choices=["auto", "on", "off"], default="auto",
                     help="send the pulled rows ahead of the pushed partial sums (two messages per peer); auto = tried both ways")
@@ -63,6 +68,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the N = 1 line")
     ap.add_argument("--no-alt-grid", action="store_true", help="N > 1: skip the second field (the same graph on feature slices, no exchange)")
     args = ap.parse_args()
+    kind, _, weight = args.cover.partition("@")
+    if kind not in ("auto", "cover", "pull") or (weight and (kind != "cover" or float(weight) < 0)):
+        ap.error("--cover: auto, cover, cover@W (W >= 0) or pull")
     if args.nodes or args.entries or args.feats:
         base = WORKLOADS[args.workload if args.workload in WORKLOADS else "config5"]
         args.nodes, args.entries, args.feats = args.nodes or base[0], args.entries or base[1], args.feats or base[2]
@@ -976,7 +984,9 @@ def main():
         # can tell: one step of every variant is timed before the timed region (max over ranks) and the timed steps run on the
         # fastest.  cover: pull/push vertex cover or the classic pull-only halo; chunks: column chunks whose exchange and SpMM
         # overlap; early_pull: the pulled rows leave as soon as they are gathered, ahead of the pushed partial sums.
-        covers = ["cover", "pull"] if args.cover == "auto" else [args.cover]
+        # plan labels: "cover" (fewest rows on the link), "cover@w" (weighted: fewer / shorter partial sums for more rows), "pull"
+        weighted = [f"cover@{float(w):g}" for w in args.push_weights.split(",") if w.strip() and float(w) > 0]
+        covers = ["cover"] + weighted + ["pull"] if args.cover == "auto" else [args.cover]
         if pv == 1:
             covers = covers[:1]                                                 # one vertex block: nothing is exchanged
         chunk_options = [k for k in (1, 2, 4) if k <= max(C_local // 32, 1)] if args.chunks <= 0 else [args.chunks]
@@ -987,7 +997,8 @@ def main():
 
         def build_plan(cover):
             t0 = time.time()
-            graphs[cover] = sharded.ShardedGraph(idx, vals, bounds, comm=comm, cover=cover, chunks=chunk_options[-1],
+            kind, _, weight = cover.partition("@")
+            graphs[cover] = sharded.ShardedGraph(idx, vals, bounds, comm=comm, cover=kind, chunks=chunk_options[-1], push_weight=float(weight or 0.0),
                                                  split_rows=not args.whole_rows, relabel=True, tune_overlap=args.overlap_probe == "on")
             torch.cuda.synchronize()
             plan_s[cover] = round(time.time() - t0, 2)
@@ -1089,7 +1100,7 @@ def main():
         halo.update(chunks=best["chunks"], early_pull=best["early_pull"], variants_timed_before_the_run=variants,
                     variants_skipped=skipped, select_seconds_budget=args.select_seconds if selecting else None,
                     overlap_probe=getattr(sg.comm, "overlap_probe", None), overlap_probe_status=getattr(sg.comm, "overlap_status", None),
-                    chosen=dict(best), pull_rows_sent=sg.n_send_pull_max, push_rows_sent=sg.n_send_push_max)
+                    chosen=dict(best), plan=best["cover"], pull_rows_sent=sg.n_send_pull_max, push_rows_sent=sg.n_send_push_max)
 
     def barrier():
         if sharded_path:
@@ -1208,7 +1219,7 @@ def main():
         else:                                                       # this rank's block: kernels alone (no exchange beside them)
             t_c = halo["compute_ms_alone"] * 1e-3 if world > 1 else sg.time_compute(state, a)
             # (the block's committed PMC passes are per plan: tools/sim_blocks.py --pmc-iterations under rocprofv3, profiles/summarize_blocks.py)
-            block_name = name + f"_block_of_{pv}_{halo['cover']}_chunks{halo['chunks']}"
+            block_name = name + f"_block_of_{pv}_{halo['plan']}_chunks{halo['chunks']}"
             roof = roofline_record(n_local, nnz_local, C_local, t_c, K, block_name, measured_peak)
             roof["note"] = "rank 0's vertex block, one iteration's kernels alone (pack + SpMM of every column chunk; no exchange beside them); " + roof["note"]
         result = {

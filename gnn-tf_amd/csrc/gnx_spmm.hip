@@ -1709,8 +1709,10 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
         if (rc != GNX_OK) return rc;
         hipLaunchKernelGGL(k_gather_vals, dim3(blocks_for(g->a.nnz, 256)), dim3(256), 0, s, d_vals ? d_vals : g->raw_vals, g->r_perm, g->a.nnz,
                            g->r_vals);
+        GNX_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_gather_rows32, dim3((unsigned)std::min<int64_t>(blocks_for(n * C, 256), 1 << 22)), dim3(256), 0, s, d_H0, C,
                            g->r_order, n, (int)C, g->r_feat, C);
+        GNX_HIP(hipGetLastError());
         const float *src = g->r_feat;
         for (int k = 0; k < K; ++k) {
             const bool last = k == K - 1;

@@ -62,91 +62,114 @@ class Dropout(Layer):
         return gcn.dropout(features, self.rate)
 
 
+def _scalar(architecture, init="zero"):
+    """A trainable [1, 1] parameter outside the weight decay (the parametrised activations' knobs)."""
+    return architecture.create_var((1, 1), init, regularize=False)
+
+
+def _scaled(architecture, **kwargs):
+    gain = _scalar(architecture)
+    return lambda x: x * (1 + gain)
+
+
+def _log_sum_of_three(architecture, **kwargs):
+    slopes = [_scalar(architecture, "ones" if i == 0 else "zero") for i in range(3)]
+    offsets = [_scalar(architecture) for _ in range(3)]
+    return lambda x: torch.logsumexp(torch.stack([x * k + c for k, c in zip(slopes, offsets)]), dim=0)
+
+
+def _soft_threshold(architecture, threshold=None, **kwargs):
+    theta = _scalar(architecture) if threshold is None else threshold
+    return lambda x: torch.relu(x - theta) - torch.relu(theta - x)
+
+
+# name -> factory(architecture, **kwargs) of the elementwise function (layers.py:139-172's names and parameter counts)
+ACTIVATIONS = {
+    "relu": lambda architecture, **kw: torch.relu,
+    "linear": lambda architecture, **kw: linear,
+    "tanh": lambda architecture, **kw: torch.tanh,
+    "exp": lambda architecture, **kw: torch.exp,
+    "softmax": lambda architecture, **kw: (lambda x: torch.softmax(x, dim=1)),
+    "scale": _scaled,
+    "kernel": _log_sum_of_three,
+    "softthresh": _soft_threshold,
+}
+
+
 class Activation(Layer):
-    """layers.py:139-172."""
+    """layers.py:139-172: a named elementwise function (some with trainable scalars), or any callable given in its place."""
 
     def __build__(self, architecture: Layered, activation: str = "relu", **kwargs):
-        if activation == "relu":
-            fn = torch.relu
-        elif activation == "linear":
-            fn = linear
-        elif activation == "tanh":
-            fn = torch.tanh
-        elif activation == "exp":
-            fn = torch.exp
-        elif activation == "softmax":
-            fn = lambda x: torch.softmax(x, dim=1)
-        elif activation == "scale":
-            scale = architecture.create_var((1, 1), "zero", regularize=False)
-            fn = lambda x: x * (1 + scale)
-        elif activation == "kernel":
-            s = [architecture.create_var((1, 1), "ones" if i == 0 else "zero", regularize=False) for i in range(6)]
-            fn = lambda x: torch.log(torch.exp(x * s[0] + s[3]) + torch.exp(x * s[1] + s[4]) + torch.exp(x * s[2] + s[5]))
-        elif activation == "softthresh":
-            theta = kwargs['threshold'] if 'threshold' in kwargs else architecture.create_var((1, 1), "zero", regularize=False)
-            fn = lambda x: torch.relu(x - theta) - torch.relu(theta - x)
-        else:
-            fn = activation
-        self.activation = fn
+        make = ACTIVATIONS.get(activation) if isinstance(activation, str) else None
+        self.activation = make(architecture, **kwargs) if make is not None else activation
         return architecture.top_shape()
 
     def __forward__(self, gcn, features):
         return self.activation(features)
 
 
-class Branch(Layer):
+# ---- flow layers (layers.py:68-122): they re-route values between layers and own no kernel of this path -------------------
+def _sources(H0):
+    """The layers a flow layer reads from: one layer or a list of them."""
+    return list(H0) if isinstance(H0, (list, tuple)) else [H0]
+
+
+class _Tap(Layer):
+    """A layer whose output is something that already exists: ``pick()`` says what; the incoming features are ignored."""
+
+    def __forward__(self, architecture: Layered, features):
+        return self.pick()
+
+
+class Branch(_Tap):
     """layers.py:68-74: restarts the flow from a given feature matrix."""
 
     def __build__(self, architecture: Layered, features):
         self.features = features
-        return tuple(self.features.shape)
-
-    def __forward__(self, architecture: Layered, features):
-        return self.features
+        self.pick = lambda: self.features
+        return tuple(features.shape)
 
 
-class Resume(Layer):
+class Resume(_Tap):
     """layers.py:77-83: continues from another layer's cached value."""
 
     def __build__(self, architecture: Layered, H0: Layer):
         self.H0 = H0
+        self.pick = lambda: self.H0.value
         return H0.output_shape
-
-    def __forward__(self, architecture: Layered, features):
-        return self.H0.value
 
 
 class Concatenate(Layer):
-    """layers.py:86-101 (including its axis-0 concatenation)."""
+    """layers.py:86-101: joins the incoming features with another layer's value, or a LIST of layers' values with each other --
+    along axis 0, although the declared output shape widens axis 1 (the reference's behaviour; NGCF's link
+    tasks index the rows of the first block)."""
 
     def __build__(self, architecture: Layered, H0):
         self.H0 = H0
-        first = H0[0] if isinstance(H0, list) else H0
-        for H in (H0 if isinstance(H0, list) else [H0]):
-            if architecture.top_shape()[0] != H.output_shape[0]:
-                raise Exception("Mismatching first dimension to concatenate between shapes " + str(architecture.top_shape())
-                                + " and " + str(H.output_shape))
-        return (architecture.top_shape()[0], architecture.top_shape()[1] + first.output_shape[1])
+        rows, width = architecture.top_shape()
+        odd = [H for H in _sources(H0) if H.output_shape[0] != rows]
+        if odd:
+            raise Exception("Mismatching first dimension to concatenate between shapes " + str(architecture.top_shape())
+                            + " and " + str(odd[0].output_shape))
+        return (rows, width + _sources(H0)[0].output_shape[1])
 
     def __forward__(self, architecture: Layered, features):
-        if isinstance(self.H0, list):
-            return torch.cat([H.value for H in self.H0], dim=0)
-        return torch.cat([features, self.H0.value], dim=0)
+        parts = [H.value for H in _sources(self.H0)]
+        return torch.cat(parts if isinstance(self.H0, list) else [features] + parts, dim=0)
 
 
 class Tradeoff(Layer):
-    """layers.py:104-122: sigmoid-weighted average of other layers' values."""
+    """layers.py:104-122: average of other layers' values with sigmoid gates, normalised to sum to one."""
 
     def __build__(self, architecture: Layered, layers, weights=None, trainable=True):
-        shape = layers[0].output_shape
-        for layer in layers:
-            if layer.output_shape != shape:
-                raise Exception("Mismatching trade-off dimentions")
+        if len({tuple(layer.output_shape) for layer in layers}) > 1:
+            raise Exception("Mismatching trade-off dimentions")
         self.layers = layers
-        self.weights = [architecture.create_var((1, 1), "zero", trainable=trainable) for _ in layers] if weights is None else weights
-        return shape
+        self.weights = weights if weights is not None else [architecture.create_var((1, 1), "zero", trainable=trainable) for _ in layers]
+        return layers[0].output_shape
 
     def __forward__(self, architecture: Layered, features):
-        gates = [torch.sigmoid(torch.as_tensor(w)) for w in self.weights]
-        total = sum(gates)
-        return sum(g * layer.value / total for g, layer in zip(gates, self.layers))
+        values = [layer.value for layer in self.layers]
+        gates = torch.sigmoid(torch.stack([torch.as_tensor(w, dtype=values[0].dtype, device=values[0].device).reshape(()) for w in self.weights]))
+        share = gates / gates.sum()
+        return sum(values[i] * share[i] for i in range(len(values)))

@@ -159,6 +159,33 @@ def test_flow_layers():
     assert c.value is a.value and t.output_shape == (5, 3)
     with pytest.raises(Exception, match="Mismatching trade-off dimentions"):
         gnntf.Layered((5, 3), [gnntf.Dense(2)]).add(gnntf.Tradeoff([a, gnntf.Layered((5, 3)).add(gnntf.Dense(2))]))
+    # un-equal gates: sigmoid(w_i) / sum sigmoid(w) (layers.py:117-122); fixed weights are taken as they are
+    fixed = arch.add(gnntf.Tradeoff([a, b], weights=[0.0, 2.0]))
+    s0, s1 = 0.5, 1 / (1 + np.exp(-2.0))
+    np.testing.assert_allclose(fixed(arch, None).detach().numpy(), ((s0 * a.value + s1 * b.value) / (s0 + s1)).detach().numpy(), rtol=1e-6)
+    # Branch restarts from a given matrix; Concatenate stacks along axis 0 while declaring a wider axis 1 (layers.py:93-101)
+    side = torch.arange(15.0).reshape(5, 3)
+    br = arch.add(gnntf.Branch(side))
+    assert br(arch, torch.zeros(1)) is side and br.output_shape == (5, 3)
+    cat = arch.add(gnntf.Concatenate(a))
+    assert cat.output_shape == (5, 6) and tuple(cat(arch, side).shape) == (10, 3) and torch.equal(cat.value[:5], side)
+    both = arch.add(gnntf.Concatenate([a, b]))
+    assert torch.equal(both(arch, None), torch.cat([a.value, b.value], dim=0))
+    with pytest.raises(Exception, match="Mismatching first dimension to concatenate"):
+        arch.add(gnntf.Concatenate(gnntf.Layered((4, 3)).add(gnntf.Dense(3))))
+    # the parametrised activations (layers.py:139-172): parameter counts, initial behaviour, formulas
+    x = torch.linspace(-2, 2, 15).reshape(5, 3)
+    for name, n_vars, want in (("scale", 1, x), ("kernel", 6, torch.log(torch.exp(x) + 2)), ("softthresh", 1, x),
+                               ("softmax", 0, torch.softmax(x, dim=1)), ("exp", 0, torch.exp(x)), ("linear", 0, x)):
+        probe = gnntf.Layered((5, 3))
+        act = probe.add(gnntf.Activation(name))
+        probe.reset()
+        assert len(act.vars) == n_vars, name
+        np.testing.assert_allclose(act(probe, x).detach().numpy(), want.numpy(), rtol=1e-6, atol=1e-7, err_msg=name)
+    thr = gnntf.Layered((5, 3))
+    np.testing.assert_allclose(thr.add(gnntf.Activation("softthresh", threshold=0.5))(thr, x).numpy(),
+                               (torch.relu(x - 0.5) - torch.relu(0.5 - x)).numpy())
+    assert gnntf.Layered((5, 3)).add(gnntf.Activation(torch.sign)).activation is torch.sign       # any callable in place of a name
 
 
 def test_npz_dataset_roundtrip(tmp_path):
