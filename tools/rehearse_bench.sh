@@ -1,14 +1,23 @@
 #!/bin/bash
-# Rehearsal of `bench.py --gpus N` on ONE card: N ranks share cuda:0 and exchange over gloo (staged through the host), on a
-# reduced graph.  Exercises everything the driver's multi-GPU run does except RCCL itself: launcher environment, plan building
-# for both halo plans, the variant table, the timed region, the self check through the exchange, the JSON line.
-# A GPU box admits at most 6 processes on its card and the launcher is one of them, so N <= 5 here; all 8 blocks of one graph run as threads of one process
-# in tests/test_gpu_fullsize.py (same plan, same kernels, exchange through shared memory).
-#   tools/rehearse_bench.sh OUTDIR [N ...]
+# Rehearsals of `bench.py --gpus N` on ONE card: N ranks share cuda:0 and exchange over gloo (staged through the host, so rates mean
+# nothing).  Exercises everything the driver's multi-GPU run does except RCCL itself: launcher environment, plan building for every
+# halo plan, the variant table, the timed region, the self check through the exchange, the JSON line.
+# A GPU box admits at most 6 processes on its card and the launcher is one of them, so N <= 5 here; all 8 blocks of one graph run as
+# threads of one process in tests/test_gpu_fullsize.py (same plan, same kernels, exchange through shared memory).
+#   tools/rehearse_bench.sh OUTDIR [N ...]          reduced graph, all-auto selection
+#   tools/rehearse_bench.sh OUTDIR exact [N]        the EXACT driver command -- `python3 bench.py --gpus N`, every option at its default
+#                                                   (config 5 at full size): what counts is that every phase runs and how long each takes
 set -o pipefail
+export TMPDIR=/tmp
 out=${1:-gpurun_out}; shift
-ranks=${@:-2 4 5}
 mkdir -p "$out"
+if [ "$1" = "exact" ]; then
+  GNX_BENCH_BACKEND=gloo timeout -k 10 1120 python3 bench.py --gpus ${2:-2} > $out/exact_gloo.json 2> $out/exact_gloo.err
+  rc=$?
+  echo "rc=$rc"; grep "^\[bench" $out/exact_gloo.err | tail -40; tail -c 1500 $out/exact_gloo.json
+  exit $rc
+fi
+ranks=${@:-2 4 5}
 for n in $ranks; do
   port=$((29600 + n))
   GNX_BENCH_BACKEND=gloo timeout -k 10 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
