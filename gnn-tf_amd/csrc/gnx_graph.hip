@@ -133,6 +133,18 @@ __global__ void k_order_keys(const int64_t *__restrict__ rowptr, int64_t n_rows,
     ids[r] = (int32_t)r;
 }
 
+// The same bins inside WINDOWS of the caller's numbering (Csr::order_window): key = (window, bin); rows without entries get the
+// window past the last one, so that they still trail the whole order (the launchers cut the order there)
+__global__ void k_order_keys_windowed(const int64_t *__restrict__ rowptr, int64_t n_rows, int clamp, int64_t window, uint32_t n_windows,
+                                      unsigned bin_bits, uint32_t *__restrict__ keys, int32_t *__restrict__ ids) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    int64_t d = rowptr[r + 1] - rowptr[r];
+    const uint32_t w = d == 0 ? n_windows : (uint32_t)(r / window);
+    keys[r] = (w << bin_bits) | (uint32_t)(clamp - (d < clamp ? d : clamp));
+    ids[r] = (int32_t)r;
+}
+
 __global__ void k_slot_ptrs(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ row_order, int64_t n_rows,
                             int64_t *__restrict__ slot_beg, int32_t *__restrict__ slot_cnt) {
     int64_t sidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -257,6 +269,21 @@ void free_csr(Csr &m) {
     m = Csr();
 }
 
+// Everything build_long_plan makes (the structure itself stays): for a rebuild under another row order
+void free_plan(Csr &m) {
+    if (m.long_rows) (void)hipFree(m.long_rows);
+    if (m.long_chunk_ptr) (void)hipFree(m.long_chunk_ptr);
+    if (m.chunk_long) (void)hipFree(m.chunk_long);
+    if (m.chunk_order) (void)hipFree(m.chunk_order);
+    if (m.row_order) (void)hipFree(m.row_order);
+    if (m.nonempty_rows) (void)hipFree(m.nonempty_rows);
+    if (m.slot_beg) (void)hipFree(m.slot_beg);
+    if (m.slot_cnt) (void)hipFree(m.slot_cnt);
+    m.long_rows = nullptr; m.long_chunk_ptr = nullptr; m.chunk_long = nullptr; m.chunk_order = nullptr; m.row_order = nullptr;
+    m.nonempty_rows = nullptr; m.slot_beg = nullptr; m.slot_cnt = nullptr;
+    m.n_long = 0; m.n_chunks = 0; m.n_nonempty = 0;
+}
+
 int build_long_plan(Csr &m, hipStream_t s) {
     m.n_long = 0; m.n_chunks = 0;
     const bool small = m.n_rows >= TINY_ROWS && m.n_rows < SMALL_ROWS;       // see gnx_internal.h
@@ -264,7 +291,25 @@ int build_long_plan(Csr &m, hipStream_t s) {
     m.long_chunk = small ? SMALL_LONG_ROW : LONG_CHUNK;
     const int order_clamp = m.long_row < 65535 ? m.long_row : 65535;
     if (m.n_rows == 0) return GNX_OK;
-    {   // degree-binned row order
+    if (m.order_window > 0) {   // degree bins inside windows of the caller's numbering
+        DevBuf k0, k1, ids, t;
+        const unsigned bin_bits = bits_for((uint64_t)order_clamp + 1);
+        const uint64_t n_windows = (uint64_t)((m.n_rows + m.order_window - 1) / m.order_window);
+        const unsigned key_bits = bin_bits + bits_for(n_windows + 1);
+        GNX_CHECK_ARG(key_bits <= 32, "row window: %lld windows of %lld rows do not fit the order key", (long long)n_windows,
+                      (long long)m.order_window);
+        GNX_HIP(k0.alloc(m.n_rows * 4)); GNX_HIP(k1.alloc(m.n_rows * 4)); GNX_HIP(ids.alloc(m.n_rows * sizeof(int32_t)));
+        GNX_HIP(hipMalloc((void **)&m.row_order, m.n_rows * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_order_keys_windowed, dim3(blocks_for(m.n_rows)), dim3(256), 0, s, m.rowptr, m.n_rows, order_clamp, m.order_window,
+                           (uint32_t)n_windows, bin_bits, k0.as<uint32_t>(), ids.as<int32_t>());
+        size_t tb = 0;
+        GNX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0.as<uint32_t>(), k1.as<uint32_t>(), ids.as<int32_t>(), m.row_order,
+                                          (size_t)m.n_rows, 0u, key_bits, s));
+        GNX_HIP(t.alloc(tb));
+        GNX_HIP(rocprim::radix_sort_pairs(t.p, tb, k0.as<uint32_t>(), k1.as<uint32_t>(), ids.as<int32_t>(), m.row_order,
+                                          (size_t)m.n_rows, 0u, key_bits, s));
+        GNX_HIP(hipStreamSynchronize(s));
+    } else {   // degree-binned row order
         DevBuf k0, k1, ids, t;
         GNX_HIP(k0.alloc(m.n_rows * 2)); GNX_HIP(k1.alloc(m.n_rows * 2)); GNX_HIP(ids.alloc(m.n_rows * sizeof(int32_t)));
         GNX_HIP(hipMalloc((void **)&m.row_order, m.n_rows * sizeof(int32_t)));
@@ -418,6 +463,7 @@ int ensure_transpose(gnx_graph *g, hipStream_t s) {
     const Csr &a = g->a;
     Csr &t = g->t;
     t.n_rows = a.n_cols; t.n_cols = a.n_rows; t.nnz = a.nnz;
+    t.order_window = a.n_rows == a.n_cols ? a.order_window : 0;     // a square graph's columns share the rows' numbering
     GNX_HIP(hipMalloc((void **)&t.rowptr, (t.n_rows + 1) * sizeof(int64_t)));
     GNX_HIP(hipMalloc((void **)&t.colidx, (t.nnz ? t.nnz : 1) * sizeof(int32_t)));
     GNX_HIP(hipMalloc((void **)&g->t_perm, (t.nnz ? t.nnz : 1) * sizeof(int32_t)));
@@ -587,7 +633,7 @@ int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream) {
         if (!g->t_mask && !g->has_dups && g->t.nnz > 0)      // the keep-bit scratch of a training step's column sums
             GNX_HIP(hipMalloc((void **)&g->t_mask, (size_t)g->t.nnz * sizeof(uint16_t)));
     }
-    if ((flags & GNX_RESERVE_K_LOOP) && C <= RELABEL_MAX_C && g->a.n_rows == g->a.n_cols && g->a.n_rows >= (1 << 20) && g->a.nnz >= g->a.n_rows) {
+    if ((flags & GNX_RESERVE_K_LOOP) && g->a.order_window == 0 && C <= RELABEL_MAX_C && g->a.n_rows == g->a.n_cols && g->a.n_rows >= (1 << 20) && g->a.nnz >= g->a.n_rows) {
         int rc = ensure_relabel(g, s);
         if (rc != GNX_OK) return rc;
         rc = ensure_relabel_features(g, (size_t)g->a.n_rows * (size_t)C * sizeof(float), s);
@@ -595,6 +641,34 @@ int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream) {
         chunks = std::max(chunks, g->r.n_chunks);
     }
     if (chunks > 0) return ensure_partial(g, (size_t)chunks * (size_t)C * sizeof(float), s);
+    return GNX_OK;
+}
+
+int gnx_graph_set_row_window(gnx_graph_t g, int64_t window_rows, void *stream) {
+    GNX_CHECK_ARG(g != nullptr, "gnx_graph_set_row_window: NULL handle");
+    GNX_CHECK_ARG(window_rows >= 0, "gnx_graph_set_row_window: negative window");
+    hipStream_t s = (hipStream_t)stream;
+    GNX_CHECK_ARG(!stream_is_capturing(s), "gnx_graph_set_row_window: the stream is being captured -- set the window before the capture begins");
+    if (g->a.order_window == window_rows) return GNX_OK;
+    GNX_HIP(hipStreamSynchronize(s));                                // launches in flight on this handle's stream still read the old order
+    const int64_t before = g->a.order_window;
+    free_plan(g->a);
+    g->a.order_window = window_rows;
+    int rc = build_long_plan(g->a, s);
+    if (rc != GNX_OK) {                                              // (a window count that does not fit the key: back to what it was)
+        free_plan(g->a);
+        g->a.order_window = before;
+        const int rc2 = build_long_plan(g->a, s);
+        return rc2 != GNX_OK ? rc2 : rc;
+    }
+    if (g->has_t) {
+        free_plan(g->t);
+        g->t.order_window = g->a.n_rows == g->a.n_cols ? window_rows : 0;
+        rc = build_long_plan(g->t, s);
+        if (rc != GNX_OK) return rc;
+    }
+    if (g->has_r) drop_relabel(g);                                   // the degree-relabelled copy belongs to the default order
+    GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
 

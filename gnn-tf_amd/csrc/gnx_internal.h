@@ -9,7 +9,7 @@
 
 #include "../../include/gnx.h"
 
-#define GNX_VERSION_NUM GNX_ABI_VERSION /* 0.4.0: the header's number */
+#define GNX_VERSION_NUM GNX_ABI_VERSION /* 0.5.0: the header's number */
 
 namespace gnx {
 
@@ -69,6 +69,10 @@ struct Csr {
     // rows in stable order of descending (clamped) entry count: the rows that share a wave in the
     // sub-wave kernels then have similar lengths (power-law graphs otherwise leave most lanes idle)
     int32_t *row_order = nullptr;       // [n_rows]
+    // gnx_graph_set_row_window: > 0 = the caller's numbering carries locality; rows are then taken in windows of this many consecutive
+    // ids (degree-binned INSIDE a window, rows without entries still trailing everything) so that the rows in flight together are
+    // neighbours in the caller's order and gather from one neighbourhood
+    int64_t order_window = 0;
     int64_t *slot_beg = nullptr;        // [n_rows] first entry of row row_order[slot] ...
     int32_t *slot_cnt = nullptr;        // [n_rows] ... and its entry count: what the sub-wave kernels read instead of rowptr[row_order[slot]]
                                         // (coalesced, and no load that depends on another load before the row's entries are known)
@@ -126,6 +130,7 @@ namespace gnx {
 
 int build_long_plan(Csr &m, hipStream_t s);
 void free_csr(Csr &m);
+void free_plan(Csr &m);
 int ensure_transpose(gnx_graph *g, hipStream_t s);
 int ensure_partial(gnx_graph *g, size_t bytes, hipStream_t s);
 bool stream_is_capturing(hipStream_t s);

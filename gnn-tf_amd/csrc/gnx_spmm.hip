@@ -1702,7 +1702,7 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
     // four to eight of the rows that receive most gathers share a line): H0 is permuted once on the way in, the LAST iteration
     // scatters its rows straight back into the caller's order.  -16..-21 % per iteration at C = 16 / 8 (RMAT 10M / 100M); the
     // sums run over a row's columns in the relabelled order, so results agree with the plain path to float32 rounding.
-    if (C <= RELABEL_MAX_C && n >= (1 << 20) && g->a.nnz >= n && d_diag == nullptr) {
+    if (C <= RELABEL_MAX_C && n >= (1 << 20) && g->a.nnz >= n && d_diag == nullptr && g->a.order_window == 0) {
         int rc = ensure_relabel(g, s);
         if (rc != GNX_OK) return rc;
         rc = ensure_relabel_features(g, (size_t)n * C * sizeof(float), s);

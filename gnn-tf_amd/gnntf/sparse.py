@@ -118,6 +118,14 @@ class DeviceGraph:
         with nat.on_device(self.device):
             nat.check(nat.lib().gnx_graph_reserve(self._h, int(C), flags, nat.current_stream()))
 
+    def set_row_window(self, window_rows):
+        """Declares that the vertex numbering of THIS graph carries locality (a community / breadth-first order): launches take the
+        rows in windows of ``window_rows`` consecutive ids (degree-binned inside a window) and narrow widths stay off the
+        degree-relabelled copy; 0 = the default global degree bins (gnx_graph_set_row_window).  Same sums, other launch order."""
+        with nat.on_device(self.device):
+            nat.check(nat.lib().gnx_graph_set_row_window(self._h, int(window_rows), nat.current_stream()))
+        self.row_window = int(window_rows)
+
     def set_dropout_counter(self, counter):
         """``counter``: a one-element int64 device tensor added to every dropout stream id used with this graph (read by the
         kernels when they run), or None.  Lets a captured training step draw fresh masks on every replay."""

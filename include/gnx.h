@@ -51,8 +51,8 @@ const char *gnx_last_error(void);
  * gnx_version() of the library it loaded and refuses a mismatch in major or minor: entry points changed argument lists under
  * the same names between 0.2 and 0.3 (gnx_halo_plan_create / _layout / _pack / _exchange gained `part` and split pull / push
  * counts; gnx_gcnii_step's d_work became d_mixed), so a 0.2 client linked against a 0.3+ library passes shifted arguments.
- * 0.4 adds gnx_graph_reserve and changes no existing signature. */
-#define GNX_ABI_VERSION 400
+ * 0.4 adds gnx_graph_reserve and changes no existing signature; 0.5 adds gnx_graph_set_row_window, likewise. */
+#define GNX_ABI_VERSION 500
 int gnx_version(void);
 
 /* ---- graph construction ------------------------------------------------------------
@@ -110,6 +110,17 @@ int gnx_graph_normalize(gnx_graph_t g, int normalized, int add_eye, float dropou
  * caller decides when it is sized.)  Nothing in the reference corresponds: TensorFlow eager allocates per op. */
 enum { GNX_RESERVE_TRANSPOSED = 1, GNX_RESERVE_K_LOOP = 2 };
 int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream);
+
+/* gnx_graph_set_row_window: the caller declares that ITS numbering of the vertices carries locality -- neighbours in the graph
+ * are neighbours in the numbering (a community / breadth-first order of the dataset; gnntf's GNN(reorder="locality") computes one).
+ * The propagation launches then take the rows in WINDOWS of `window_rows` consecutive ids -- inside a window still in the
+ * degree-binned order that gives the rows sharing a wave equal lengths -- so that the rows in flight together gather from one
+ * neighbourhood of H (at narrow widths a gather moves a whole 128-byte line for a 16..160-byte row: what counts is how often the
+ * line is still in a cache), and gnx_appnp_propagate does NOT run narrow widths on its degree-relabelled copy, which would scatter
+ * that neighbourhood.  0 restores the default (global degree bins).  Results are the same sums in the same per-row order: bitwise
+ * those of the default order except where the default would have used the relabelled copy.  Rebuilds the handle's launch plan:
+ * synchronises the stream, not capturable.  Nothing in the reference corresponds (TensorFlow's kernel walks the COO as stored). */
+int gnx_graph_set_row_window(gnx_graph_t g, int64_t window_rows, void *stream);
 
 /* gnx_graph_set_dropout_counter: from now on every dropout stream id used with this handle is `stream_id + *d_counter`
  * (d_counter: one uint64 in device memory, read by the kernels when they run; NULL switches it off).  This is what lets a

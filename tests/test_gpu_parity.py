@@ -699,6 +699,47 @@ def test_model_level_degree_reorder(gnntf, golden_dir):
         gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, reorder="rcm")
 
 
+@pytest.mark.parametrize("n,entries", [(3000, 30000), (40000, 500000)])
+def test_row_window_changes_the_launch_order_not_the_sums(gnntf, n, entries):
+    """gnx_graph_set_row_window: rows taken in windows of the caller's numbering (degree-binned inside a window).  Every row's sum
+    runs over the same entries in the same order, so a single launch, its transposed form, the K loop, a training launch and the
+    GCNII launch are bitwise what the default order gives; 0 restores the default; the oracle agrees."""
+    coo, vals, shape = graphs.rmat_symmetric_coo(n, entries, seed=6)
+    coo = np.concatenate([coo, np.stack([np.full(900, 7), np.arange(900) + 11], 1), np.stack([np.arange(900) + 11, np.full(900, 7)], 1)])   # a long row / column
+    vals = np.concatenate([vals, np.ones(1800, dtype=np.float32)])
+    rng = np.random.default_rng(0)
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(coo, vals, shape), device="cuda:0")
+    adj = gnntf.normalize(g, "symmetric")
+    M = dev((0.5 * np.eye(32) + rng.standard_normal((32, 32)) * 0.2).astype(np.float32))
+
+    def everything():
+        out = {}
+        for C in (7, 8, 40, 64, 256):
+            H0 = dev(np.random.default_rng(C).standard_normal((n, C)).astype(np.float32))
+            out[C, "step"] = gnntf.ppr_step(adj, H0, H0, 0.1)
+            out[C, "loop"] = gnntf.appnp_propagate(adj, H0, 0.1, 4)
+            out[C, "t"] = gnntf.sparse._launch(adj, H0, None, 1.0, 0.0, 0, transposed=True)
+            out[C, "drop"] = gnntf.sparse._launch(gnntf.sparse.dropped_adjacency(g, 0.5, 3, 1), H0, H0, 0.9, 0.1, 0)
+        H = dev(np.random.default_rng(1).standard_normal((n, 32)).astype(np.float32))
+        with torch.no_grad():
+            out["gcnii"] = gnntf.gcnii_step(adj, H, H, 0.1, M, relu=True)
+        return out
+    base = everything()
+    for window in (64, 1000, n + 5):
+        g.set_row_window(window)
+        got = everything()
+        for key in base:
+            assert torch.equal(got[key], base[key]), (window, key, float((got[key] - base[key]).abs().max()))
+    H0 = np.random.default_rng(8).standard_normal((n, 8)).astype(np.float32)
+    want = orc.appnp_propagate(coo, vals, shape, H0, a=0.1, iterations=4)
+    np.testing.assert_allclose(gnntf.appnp_propagate(adj, dev(H0), 0.1, 4).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    g.set_row_window(0)
+    again = everything()
+    assert all(torch.equal(again[key], base[key]) for key in base)
+    with pytest.raises(Exception, match="negative window"):
+        g.set_row_window(-1)
+
+
 def test_gcnii_layer_api(gnntf):
     """GCNII reuses the fused SpMM+mix kernel (gcn.py:7-27,54-74)."""
     coo, vals, shape = graphs.rmat_symmetric_coo(1500, 12000, seed=4)

@@ -1,34 +1,54 @@
 #!/bin/bash
-# do the narrow-width locality orders pay on a COMMUNITY-structured graph (planted partition x power-law degrees,
-# N = 10M, 100M entries, randomly relabelled -- tools/narrow_order_experiment.py --graph community)?  Times the K = 10 loop at
-# C = 7 / 8 / 40 under every order, then takes FETCH_SIZE / WRITE_SIZE passes at C = 8 for the bench labelling, the BFS order and the
-# generator's own communities.  Kill criterion: BFS not below 1.6 x B_alg at C = 8.
-#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh [outdir]'
+# do locality orders pay at the narrow widths on a COMMUNITY-structured graph (planted partition x power-law
+# degrees, N = 10M, ~100M entries, randomly relabelled -- tools/narrow_order_experiment.py --graph community)?
+#   part "bins"    (round 5, first visit): the orders INSIDE the library's global degree bins, as round 4 tried on R-MAT
+#   part "windows" the orders handed over as locality orders (gnx_graph_set_row_window): rows taken in windows of the numbering
+# Each part times the K = 10 loop at C = 7 / 8 / 40 / 64 and takes FETCH_SIZE / WRITE_SIZE passes at C = 8.
+#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows]'
 export TMPDIR=/tmp
 O=${1:-gpurun_out/r5b}
+PART=${2:-windows}
 mkdir -p $O
-timeout -k 10 400 python3 tools/narrow_order_experiment.py --graph community --feats 7,8,40 > $O/community_timing.jsonl 2> $O/community_timing.err || { echo timing failed; tail -5 $O/community_timing.err; exit 1; }
-cat $O/community_timing.jsonl | cut -c1-260
-timeout -k 10 300 python3 tools/narrow_order_experiment.py --graph community --feats 40,64 --pure --only bfs,planted > $O/community_timing_pure.jsonl 2> $O/community_timing_pure.err || { echo pure timing failed; exit 1; }
-cat $O/community_timing_pure.jsonl | cut -c1-260
-for order in workload bfs planted; do
+T=tools/narrow_order_experiment.py
+
+fetch_pass() {   # LABEL then the tool's arguments: FETCH_SIZE + WRITE_SIZE passes, bytes per launch appended to $O/fetch_C8.jsonl
+  local label=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rm -rf $O/pmc_${order}_$ctr
-    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${order}_$ctr -o run -- python3 tools/narrow_order_experiment.py --graph community --feats 8 --only $order --rounds 1 \
-        > $O/pmc_${order}_$ctr.json 2> $O/pmc_${order}_$ctr.err || { echo "$order $ctr failed"; tail -5 $O/pmc_${order}_$ctr.err; exit 1; }
+    rm -rf $O/pmc_${label}_$ctr
+    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $O/pmc_${label}_$ctr -o run -- python3 $T "$@" --rounds 1 \
+        > $O/pmc_${label}_$ctr.json 2> $O/pmc_${label}_$ctr.err || { echo "$label $ctr failed"; tail -5 $O/pmc_${label}_$ctr.err; return 1; }
   done
-  python3 - "$O" "$order" <<'PY'
+  python3 - "$O" "$label" <<'PY'
 import glob, json, os, sys
 sys.path.insert(0, os.getcwd())
 import bench
-O, order = sys.argv[1:3]
+O, label = sys.argv[1:3]
 one = lambda d: max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
-total = bench.fabric_bytes_per_launch(one(f"{O}/pmc_{order}_FETCH_SIZE"), one(f"{O}/pmc_{order}_WRITE_SIZE"))
-rec = json.loads(open(f"{O}/pmc_{order}_FETCH_SIZE.json").read().strip().splitlines()[-1])
-line = dict(order=order, C=8, fabric_GB_per_launch=total / 1e9, alg_GB_per_launch=rec["alg_GB_per_launch"], ratio=total / 1e9 / rec["alg_GB_per_launch"])
+total = bench.fabric_bytes_per_launch(one(f"{O}/pmc_{label}_FETCH_SIZE"), one(f"{O}/pmc_{label}_WRITE_SIZE"))
+rec = json.loads(open(f"{O}/pmc_{label}_FETCH_SIZE.json").read().strip().splitlines()[-1])
+line = dict(run=label, graph=rec["graph"], order=rec["order"], window=rec.get("window", 0), C=rec["C"], ms_per_K10_under_the_profiler=rec["ms_per_K10"],
+            fabric_GB_per_launch=total / 1e9, alg_GB_per_launch=rec["alg_GB_per_launch"], ratio=total / 1e9 / rec["alg_GB_per_launch"])
 print(json.dumps(line))
-open(f"{O}/community_fetch_C8.jsonl", "a").write(json.dumps(line) + "\n")
+open(f"{O}/fetch_C8.jsonl", "a").write(json.dumps(line) + "\n")
 PY
-done
-find $O -name "*_counter_collection.csv" -size +30M -delete
-echo "community experiment done"
+  find $O/pmc_${label}_* -name "*_counter_collection.csv" -size +30M -delete
+}
+
+if [ "$PART" = "bins" ]; then
+  timeout -k 10 400 python3 $T --graph community --feats 7,8,40 > $O/community_timing.jsonl 2> $O/community_timing.err || { echo timing failed; tail -5 $O/community_timing.err; exit 1; }
+  cut -c1-260 $O/community_timing.jsonl
+  for order in workload bfs planted; do fetch_pass bins_$order --graph community --feats 8 --only $order || exit 1; done
+else
+  timeout -k 10 500 python3 $T --graph community --window 65536 --feats 7,8,40,64 --only workload,planted,lpa,bfs > $O/windows_community_w64k.jsonl 2> $O/windows_community_w64k.err \
+      || { echo "community windows failed"; tail -5 $O/windows_community_w64k.err; exit 1; }
+  cut -c1-300 $O/windows_community_w64k.jsonl
+  for W in 16384 262144 1048576; do
+    timeout -k 10 300 python3 $T --graph community --window $W --feats 8,40 --only planted,lpa > $O/windows_community_w$W.jsonl 2> $O/windows_community_w$W.err || { echo "window $W failed"; exit 1; }
+    cut -c1-300 $O/windows_community_w$W.jsonl
+  done
+  timeout -k 10 400 python3 $T --graph rmat --window 65536 --feats 8,40 --only workload,lpa,bfs > $O/windows_rmat_w64k.jsonl 2> $O/windows_rmat_w64k.err || { echo "rmat windows failed"; exit 1; }
+  cut -c1-300 $O/windows_rmat_w64k.jsonl
+  fetch_pass windows_planted --graph community --window 65536 --feats 8 --only planted || exit 1
+  fetch_pass windows_lpa --graph community --window 65536 --feats 8 --only lpa || exit 1
+fi
+echo "community experiment ($PART) done"

@@ -92,6 +92,20 @@ def community_pairs(n, m, seed, device, mix=0.2, gamma=2.5, tau=2.0, size_lo=64,
     return perm[u], perm[v], comm_final
 
 
+def lpa_labels(src, dst, n, rounds=4):
+    """Synchronous label propagation: every vertex takes the label most of its neighbours carry (ties: the larger label), for a few
+    rounds from singleton labels -- a cheap community guess whose only use here is as a sort key."""
+    dev = src.device
+    label = torch.arange(n, device=dev)
+    for _ in range(rounds):
+        pair, counts = torch.unique(dst * n + label[src], return_counts=True)          # (vertex, neighbour label) -> how many neighbours
+        best = torch.zeros(n, dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, torch.div(pair, n, rounding_mode="floor"), counts * n + pair % n, reduce="amax")
+        label = torch.where(best > 0, best % n, label)
+        del pair, counts, best
+    return label
+
+
 def tail_key(name, u, v, n, deg, comm=None):
     """int64 [n]: the secondary sort key inside a degree bin."""
     dev = u.device
@@ -107,6 +121,9 @@ def tail_key(name, u, v, n, deg, comm=None):
         return key, {}
     if name == "planted":                                                # the generator's own communities: the best any locality order can do
         return comm.clone(), {}
+    if name == "lpa":
+        label = lpa_labels(src, dst, n)
+        return label, {"lpa_labels": int(torch.unique(label).numel())}
     if name == "bfs":
         pos, levels = bfs_positions(src, dst, n, int(order[0]))
         return pos, {"bfs_levels": levels, "bfs_reached": int((pos < INF).sum())}
@@ -123,6 +140,9 @@ def main():
     ap.add_argument("--graph", choices=["rmat", "community"], default="rmat",
                     help="rmat: the bench graph (config 4); community: planted partition x power-law degrees (community_pairs), same N / entries")
     ap.add_argument("--mix", type=float, default=0.2, help="community graph: share of the pairs that leave their community")
+    ap.add_argument("--window", type=int, default=0,
+                    help="> 0: hand the library the order as a LOCALITY order -- gnx_graph_set_row_window(window): rows taken in windows of this many "
+                         "consecutive ids, degree-binned inside a window, no degree-relabelled copy (implies --pure for every order but workload)")
     ap.add_argument("--pure", action="store_true", help="order by the tail key ALONE (no degree bins in front of it) -- for C > 16, where the library does not relabel")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -142,7 +162,7 @@ def main():
         if name == "workload":
             newid = None
         else:
-            bin_ = torch.zeros_like(deg) if a.pure else 512 - deg.clamp(max=512)      # the library's degree bins (heaviest first)
+            bin_ = torch.zeros_like(deg) if (a.pure or a.window > 0) else 512 - deg.clamp(max=512)      # the library's degree bins (heaviest first)
             k1 = torch.argsort(key, stable=True)                          # lexicographic (bin, key, old id) by two stable sorts
             order = k1[torch.argsort(bin_[k1], stable=True)]
             newid = torch.empty_like(order)
@@ -153,6 +173,8 @@ def main():
         idx = torch.cat([torch.stack([uu, vv], 1), torch.stack([vv, uu], 1)])
         g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=dev), (n, n)), device=dev)
         del idx, uu, vv, key
+        if a.window > 0 and name != "workload":
+            g.set_row_window(a.window)
         adj = gnntf.normalize(g, "symmetric")
         for C in [int(c) for c in a.feats.split(",")]:
             gen = torch.Generator(device=dev).manual_seed(2)
@@ -169,7 +191,7 @@ def main():
                     times.append(s.elapsed_time(e))
             ms = sorted(times)[len(times) // 2]
             b = bench.alg_bytes_per_iteration(n, g.nnz, C)
-            print(json.dumps(dict(graph=a.graph, entries=g.nnz, empty_rows=int((deg == 0).sum()), max_degree=int(deg.max()), pure=a.pure,
+            print(json.dumps(dict(graph=a.graph, entries=g.nnz, empty_rows=int((deg == 0).sum()), max_degree=int(deg.max()), pure=a.pure, window=(a.window if name != "workload" else 0),
                                   order=name, C=C, ms_per_K10=ms, kernel=g.last_kernel(), alg_frac_of_8TBs=b * K / ms / 1e6 / 8000, alg_GB_per_launch=b / 1e9,
                                   order_seconds=round(t_order, 2), checksum=float(out.double().sum()), **info)), flush=True)
             del H0, out, work
