@@ -204,13 +204,25 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
     else vstore<VEC>(p.out + orow * p.ldo + c, o);
 }
 
+// Which block of row slots this workgroup takes.  Default: its own index.  With a locality order (SpmmArgs::xcd_contig) the index
+// is remapped so that the workgroups the dispatcher places on one XCD (observed: round-robin, blockIdx % 8 -- a speed assumption,
+// never a correctness one: the map is a bijection of the grid whatever the placement) walk one contiguous eighth of the slots: the
+// eight private L2s then hold eight different neighbourhoods of H instead of eight copies of the same one
+// (cdna_hip_programming.md T1, bijective form for grids that are not a multiple of 8).
+__device__ __forceinline__ int64_t xcd_block(const SpmmArgs &p) {
+    const uint32_t b = blockIdx.x;
+    if (!p.xcd_contig) return (int64_t)b;
+    const uint32_t n = gridDim.x, q = n >> 3, r = n & 7u, x = b & 7u;
+    return (int64_t)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3));
+}
+
 // ---- wide path: one wave per row -----------------------------------------------------------
 // tune bits (GNX_TUNE, experiments): 1 = degree-binned row order, 2 = non-temporal H0/out, 4 = non-temporal col/val
 template <int VEC, int U, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_spmm_wave(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t slot = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
+    const int64_t slot = p.slot0 + xcd_block(p) * WPB + wib;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_list ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_list[slot])
                                    : ((p.tune & 1) ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_order[slot]) : slot);
@@ -365,8 +377,8 @@ __device__ __forceinline__ void group_rows_coop(const SpmmArgs &p, int64_t block
 
 template <int VEC, int G, int U, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
-    if (G <= 8 && !(p.tune & 32768)) group_rows_coop<VEC, G, 4>(p, blockIdx.x);     // (tune bit: tuning builds' A/B switch back to the per-lane fetch)
-    else group_rows<VEC, G, U, PIPE>(p, blockIdx.x);
+    if (G <= 8 && !(p.tune & 32768)) group_rows_coop<VEC, G, 4>(p, xcd_block(p));     // (tune bit: tuning builds' A/B switch back to the per-lane fetch)
+    else group_rows<VEC, G, U, PIPE>(p, xcd_block(p));
 }
 
 // ---- GCNII layer: SpMM + mix + C x C transform on the matrix cores + activation, one launch ------------------------
@@ -881,7 +893,7 @@ template <int VEC, int U, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_spmm_wave_drop(const SpmmArgs p) {
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t slot = p.slot0 + (int64_t)blockIdx.x * WPB + wib;
+    const int64_t slot = p.slot0 + xcd_block(p) * WPB + wib;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_list ? (int64_t)__builtin_amdgcn_readfirstlane(p.row_list[slot]) : slot;
     const int64_t beg = p.rowptr[row], end = p.rowptr[row + 1];
@@ -904,7 +916,7 @@ template <int VEC, int G, int U, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group_drop(const SpmmArgs p) {
     constexpr int RPB = 256 / G;
     const int sub = threadIdx.x % G;
-    const int64_t slot = p.slot0 + (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+    const int64_t slot = p.slot0 + xcd_block(p) * RPB + threadIdx.x / G;
     if (slot >= p.n_rows) return;
     const int64_t row = p.row_order ? (int64_t)p.row_order[slot] : slot;
     int64_t beg, end;
@@ -1338,6 +1350,7 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.slot_beg = m.slot_beg; p.slot_cnt = m.slot_cnt;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
+    p.xcd_contig = m.order_window > 0;
     p.chunk_order = m.chunk_order;
 #ifdef GNX_TUNING   // kernel-variant switches exist only in tuning builds (tools/tune_spmm.py); the product library has none
     {
