@@ -687,6 +687,53 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         del hand, H0l, X, fused_out, by_layer
         torch.cuda.empty_cache()
     out["config4_via_layer_api"] = via_api
+    # a graph WITH communities (planted partition x power-law degrees, same N, ~ the same entries: the structure the reference's
+    # citation datasets have and R-MAT lacks): gnntf.APPNP in its default order against GNN(reorder="locality") -- label propagation
+    # order + row windows (gnx_graph_set_row_window) -- at the widths gnntf's APPNP propagates; same model, same weights, the
+    # outputs compared in the caller's order; prep = what the reordered model's construction costs beyond the plain one's
+    from gnntf.rmat import community_pairs
+    u, v, _ = community_pairs(n4, e4 // 2, 1, device)
+    cidx = torch.cat([torch.stack([u, v], 1), torch.stack([v, u], 1)])
+    del u, v
+    ccoo = gnntf.SparseCOO(cidx, torch.ones(cidx.shape[0], device=device), (n4, n4))
+    Xc = torch.randn(n4, 16, device=device)
+    comm_rec = {"what": "planted-partition x power-law graph (gnntf.rmat.community_pairs: communities of 64 ... 65536 vertices, 20 % of the pairs "
+                        "leave their community, vertices randomly relabelled), gnntf.APPNP(..., latent_dims=[]) in eval mode: the K PPRIteration "
+                        "layers alone (architecture.run(H0, first=2)), default order against reorder=\"locality\"", "widths": []}
+    for C in (40, 8):
+        per = {"C": C}
+        outs = {}
+        for reorder in (None, "locality"):
+            gnntf.set_seed(0)
+            torch.manual_seed(0)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            cm = gnntf.APPNP(ccoo, Xc, num_classes=C, latent_dims=[], iterations=K, a=a, reorder=reorder)
+            torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+            cm.reset()
+            cm.training_mode(False)
+            with torch.no_grad():
+                outs[reorder] = cm(cm.features)
+                H0c = cm.layers()[1].value
+                ms = median_ms(lambda: cm.run(H0c, first=2), reps=3, warm=1)
+            key = "locality" if reorder else "default"
+            per[key + "_ms"], per[key + "_build_s"], per[key + "_kernel"] = ms, t_build, cm.graph.last_kernel()
+            if reorder:
+                per["reorder_used"], per["locality_share"], per["entries"] = cm.reorder_used, cm.locality_share, cm.graph.nnz
+            for layer in cm.layers():
+                layer.value = None
+            del cm, H0c
+            torch.cuda.empty_cache()
+        per["max_abs_difference_of_the_outputs"] = float((outs[None] - outs["locality"]).abs().max())
+        per["argmax_equal_share"] = float((outs[None].argmax(1) == outs["locality"].argmax(1)).float().mean())
+        per["time_ratio"] = per["locality_ms"] / per["default_ms"]
+        comm_rec["widths"].append(per)
+        flat.update({f"community_graph_C{C}_default_ms": per["default_ms"], f"community_graph_C{C}_locality_order_ms": per["locality_ms"],
+                     f"community_graph_C{C}_locality_prep_s": per["locality_build_s"] - per["default_build_s"]})
+        del outs
+    flat.update(community_graph_locality_share=comm_rec["widths"][0]["locality_share"], community_graph_entries=comm_rec["widths"][0]["entries"])
+    out["community_graph_locality_order"] = comm_rec
+    del cidx, ccoo, Xc
+    torch.cuda.empty_cache()
     # training-mode step: K = 10 iterations, each with its own dropped + re-normalised adjacency,
     # forward + backward through the fused loop node (masks regenerated in the backward), C = 64
     C = 64

@@ -218,8 +218,8 @@ struct SpmmArgs {
     int long_row, long_chunk;
     int tune;
     bool skip_empty;           // GNX_ACT_SKIP_EMPTY: rows without entries are left untouched
-    bool xcd_contig;           // the row order carries locality (Csr::order_window > 0): the blocks that share an XCD take a CONTIGUOUS
-                               // eighth of the row slots (xcd_block), so that every L2 caches its own neighbourhood of H
+    int64_t xcd_rows;          // > 0: the row order carries locality (= Csr::order_window): the blocks that share an XCD take whole CHUNKS
+    uint32_t xcd_chunk;        // of xcd_chunk consecutive blocks = one window's worth of slots (xcd_block; set per launch from xcd_rows)
     DropFuse fuse;
 };
 

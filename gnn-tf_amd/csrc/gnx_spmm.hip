@@ -204,16 +204,20 @@ __device__ __forceinline__ void epilogue_store(const SpmmArgs &p, int64_t row, i
     else vstore<VEC>(p.out + orow * p.ldo + c, o);
 }
 
-// Which block of row slots this workgroup takes.  Default: its own index.  With a locality order (SpmmArgs::xcd_contig) the index
+// Which block of row slots this workgroup takes.  Default: its own index.  With a locality order (SpmmArgs::xcd_rows > 0) the index
 // is remapped so that the workgroups the dispatcher places on one XCD (observed: round-robin, blockIdx % 8 -- a speed assumption,
-// never a correctness one: the map is a bijection of the grid whatever the placement) walk one contiguous eighth of the slots: the
-// eight private L2s then hold eight different neighbourhoods of H instead of eight copies of the same one
-// (cdna_hip_programming.md T1, bijective form for grids that are not a multiple of 8).
+// never a correctness one: the map is a bijection of the padded grid whatever the placement) take whole CHUNKS of xcd_chunk
+// consecutive blocks, chunk j * 8 + x going to group x: an XCD then works on one contiguous stretch of the numbering at a time and
+// its L2 holds THAT neighbourhood of H, instead of every L2 holding a slice of everything in flight (cdna_hip_programming.md T1).
+// A chunk is one WINDOW's worth of slots: inside a window the rows are sorted by length, so any finer chunk hands the same XCDs the
+// heavy part of every window (measured: chunks of a quarter window 2 x slower on orders with heavy heads), and contiguous eighths
+// of the whole order hold unequal work (profiles/NOTES.md round 5).  The launcher pads the grid to a multiple of 8 chunks; padded
+// blocks map past the last slot and leave.
 __device__ __forceinline__ int64_t xcd_block(const SpmmArgs &p) {
     const uint32_t b = blockIdx.x;
-    if (!p.xcd_contig) return (int64_t)b;
-    const uint32_t n = gridDim.x, q = n >> 3, r = n & 7u, x = b & 7u;
-    return (int64_t)((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3));
+    if (p.xcd_rows <= 0) return (int64_t)b;
+    const uint32_t x = b & 7u, i = b >> 3, ch = p.xcd_chunk;
+    return ((int64_t)(i / ch) * 8 + x) * ch + i % ch;
 }
 
 // ---- wide path: one wave per row -----------------------------------------------------------
@@ -1187,7 +1191,14 @@ int pick_vec(const SpmmArgs &p) {
             SpmmArgs q_ = p;                                                                                                \
             q_.slot0 = r0_;                                                                                                 \
             const int64_t rows_ = p.n_rows - r0_ < per_launch_ ? p.n_rows - r0_ : per_launch_;                               \
-            hipLaunchKernelGGL(kern, dim3(blocks_for(rows_, rows_per_block)), dim3(threads), 0, s, q_);                      \
+            q_.n_rows = r0_ + rows_;    /* a piece ends where the next begins (padded blocks of the XCD map must not run on) */       \
+            unsigned grid_ = blocks_for(rows_, rows_per_block);                                                             \
+            if (q_.xcd_rows > 0) {     /* xcd_block: whole chunks, the grid padded to 8 of them */                           \
+                q_.xcd_chunk = (uint32_t)((q_.xcd_rows + (rows_per_block) - 1) / (rows_per_block));                          \
+                const unsigned span_ = 8u * q_.xcd_chunk;                                                                   \
+                grid_ = (grid_ + span_ - 1) / span_ * span_;                                                                \
+            }                                                                                                               \
+            hipLaunchKernelGGL(kern, dim3(grid_), dim3(threads), 0, s, q_);                                                  \
         }                                                                                                                   \
     } while (0)
 
@@ -1350,7 +1361,7 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
     p.slot_beg = m.slot_beg; p.slot_cnt = m.slot_cnt;
     p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long;
     p.row_order = m.row_order;
-    p.xcd_contig = m.order_window > 0;
+    p.xcd_rows = m.order_window;
     p.chunk_order = m.chunk_order;
 #ifdef GNX_TUNING   // kernel-variant switches exist only in tuning builds (tools/tune_spmm.py); the product library has none
     {

@@ -13,7 +13,7 @@ import math
 
 import torch
 
-from . import sparse
+from . import ordering, sparse
 from .blocks import Concatenate, Dense, Dropout, affine, linear, relu
 from .params import default_device
 from .protocol import Layer
@@ -42,30 +42,52 @@ class GNN(Trainable):
     """gnn.py:29-50."""
 
     def __init__(self, graph, features, preprocessor: Layer = None, reorder=None):
-        """``reorder="degree"`` (opt-in, not in the reference): store the graph and the feature rows with the
-        vertices relabelled in stable order of descending entry count.  Every [N, .] tensor inside the model then
-        lives in that order (5-20 % faster propagation at C <= 128: rows sharing a wave, their H0/out rows and the
-        hub rows become neighbours in memory); the model's OUTPUT is put back into the caller's order, so tasks,
-        labels and node ids are unaffected.  Results agree with the unordered model to float32 rounding."""
+        """``reorder`` (opt-in, not in the reference): store the graph and the feature rows with the vertices relabelled; every
+        [N, .] tensor inside the model then lives in that order, and the model's OUTPUT is put back into the caller's order, so
+        tasks, labels and node ids are unaffected.  Results agree with the unordered model to float32 rounding.
+        ``"degree"``: stable order of descending entry count (5-20 % faster propagation at C <= 128: rows sharing a wave, their
+        H0/out rows and the hub rows become neighbours in memory).
+        ``"locality"``: community by community (gnntf.ordering.locality_order: label propagation) with the library told so
+        (row windows, one window of the numbering per XCD at a time) -- for graphs that HAVE communities, as the reference's
+        citation datasets do: -14 ... -26 % per propagation at C = 7 ... 256 on a planted-partition x power-law graph of 10M
+        vertices.  On a graph without communities (R-MAT) the order finds none (``locality_share`` below
+        ordering.LOCALITY_MIN_SHARE) and the model keeps the default order (``reorder_used`` is then None).
+        Measurements: profiles/NOTES.md round 5."""
         super().__init__(features)
         self._order = self._newid = None
+        self.reorder_used, self.locality_share = None, None
         if isinstance(graph, sparse.DeviceGraph):
             if reorder is not None:
                 raise Exception("GNN: reorder needs the COO adjacency, not a ready DeviceGraph")
             self.graph = graph
         else:
             coo = sparse.as_coo(graph).to(default_device())
-            if reorder == "degree":
-                n = coo.dense_shape[0]
-                entries = torch.bincount(coo.indices[:, 0], minlength=n)
-                self._order = torch.argsort(entries, descending=True, stable=True)          # new id -> old id
-                self._newid = torch.empty_like(self._order)
-                self._newid[self._order] = torch.arange(n, device=self._order.device)
-                coo = sparse.SparseCOO(self._newid[coo.indices], coo.values, coo.dense_shape)
-                self.features = self.features.index_select(0, self._order)
-            elif reorder is not None:
+            if reorder not in (None, "degree", "locality"):
                 raise Exception("Invalid reorder option")
+            n = coo.dense_shape[0]
+            order = None
+            if reorder == "degree":
+                order = torch.argsort(torch.bincount(coo.indices[:, 0], minlength=n), descending=True, stable=True)    # new id -> old id
+            elif reorder == "locality":
+                if coo.dense_shape[0] != coo.dense_shape[1]:
+                    raise Exception("GNN: reorder=\"locality\" needs a square adjacency")
+                order = ordering.locality_order(coo.indices, n)
+            if order is not None:
+                newid = torch.empty_like(order)
+                newid[order] = torch.arange(n, device=order.device)
+                if reorder == "locality":
+                    # did the order find communities?  On a graph without them (R-MAT) it is a loss against the default: keep that
+                    self.locality_share = ordering.share_within(coo.indices, newid, ordering.LOCALITY_WINDOW)
+                    if self.locality_share < ordering.LOCALITY_MIN_SHARE:
+                        order, reorder = None, None
+            self.reorder_used = reorder
+            if order is not None:
+                self._order, self._newid = order, newid
+                coo = sparse.SparseCOO(newid[coo.indices], coo.values, coo.dense_shape)
+                self.features = self.features.index_select(0, order)
             self.graph = sparse.DeviceGraph(coo, device=default_device())
+            if reorder == "locality":
+                self.graph.set_row_window(ordering.LOCALITY_WINDOW)
         self._adjacency_cache = dict()
         if preprocessor is not None:
             self.add(preprocessor)

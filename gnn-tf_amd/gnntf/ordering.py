@@ -1,0 +1,48 @@
+"""Vertex orders for ``GNN(reorder=...)`` -- not in the reference (TensorFlow's kernel walks the COO as stored); a legal
+preprocessing step of the graph ingest ("vertex reordering"), counted as prep time.
+
+``locality_order``: a numbering in which neighbours in the graph are neighbours in memory, for graphs that HAVE communities
+(citation / co-purchase graphs such as the reference's Cora, Citeseer, Pubmed, ogbn-arxiv: experiments/experiment_setup.py:153-181).
+A few rounds of synchronous label propagation guess the communities; vertices are then numbered community by community.  The
+library is told so (gnx_graph_set_row_window): it takes the rows in windows of that numbering and gives the workgroups of one XCD
+a contiguous stretch of it, so that each L2 holds the rows of H its own communities gather.  What it gives and where it loses
+(R-MAT has no communities: the degree order of the default is better there) is in profiles/NOTES.md, round 5.
+Pure torch: runs wherever the index tensors live."""
+from __future__ import annotations
+
+import torch
+
+LOCALITY_WINDOW = 4096           # rows per window handed to gnx_graph_set_row_window (measured 4096 ... 65536: profiles/NOTES.md round 5)
+LOCALITY_MIN_SHARE = 0.1         # below this share of entries between vertices less than a window apart the order found no communities
+                                 # (community graph: 0.36, R-MAT: 0.002) and the model keeps the default order instead
+
+
+def propagate_labels(rows: torch.Tensor, cols: torch.Tensor, n: int, rounds: int = 4) -> torch.Tensor:
+    """Synchronous label propagation over the stored entries (row <- col): every vertex takes the label most of its neighbours
+    carry (ties: the larger label), ``rounds`` times from singleton labels.  Vertices without entries keep their own label."""
+    label = torch.arange(n, device=rows.device)
+    rows, cols = rows.to(torch.int64), cols.to(torch.int64)
+    for _ in range(rounds):
+        pair, counts = torch.unique(rows * n + label[cols], return_counts=True)         # (vertex, neighbour label) -> neighbours carrying it
+        best = torch.zeros(n, dtype=torch.int64, device=rows.device)
+        best.scatter_reduce_(0, torch.div(pair, n, rounding_mode="floor"), counts * n + pair % n, reduce="amax")
+        label = torch.where(best > 0, best % n, label)
+    return label
+
+
+def locality_order(indices: torch.Tensor, n: int, rounds: int = 4) -> torch.Tensor:
+    """new id -> old id.  Vertices with entries first, grouped by their propagated label (groups in ascending label order, inside a
+    group heaviest first, then by old id); vertices without entries last."""
+    rows, cols = indices[:, 0], indices[:, 1]
+    degree = torch.bincount(rows, minlength=n)
+    label = propagate_labels(rows, cols, n, rounds)
+    order = torch.argsort(degree, descending=True, stable=True)                       # by degree ...
+    order = order[torch.argsort(label[order], stable=True)]                           # ... inside a label ...
+    return order[torch.argsort((degree[order] == 0).to(torch.int8), stable=True)]     # ... and the empty rows behind everything
+
+
+def share_within(indices: torch.Tensor, newid: torch.Tensor, window: int) -> float:
+    """Share of the stored entries whose two vertices are less than ``window`` positions apart under the numbering ``newid``."""
+    if indices.shape[0] == 0:
+        return 0.0
+    return float(((newid[indices[:, 0]] - newid[indices[:, 1]]).abs() < window).float().mean())

@@ -1,4 +1,5 @@
-"""Synthetic R-MAT workloads of bench.py: the generator of SURVEY.md 8(d) ((a, b, c, d) = (0.57, 0.19, 0.19, 0.05), ids folded onto
+"""Synthetic workloads of bench.py.  community_pairs: a planted-partition x power-law graph (the structure citation graphs have and
+R-MAT lacks), for the locality order.  R-MAT: the generator of SURVEY.md 8(d) ((a, b, c, d) = (0.57, 0.19, 0.19, 0.05), ids folded onto
 n vertices, self loops dropped, exactly the requested number of undirected edges, random relabelling) on the device, and the two
 ways of turning it into vertex blocks -- ONE global graph cut into pv blocks (strong scaling, the bench's N > 1 workload) and a
 graph grown with the world size (weak scaling, kept for tests and rehearsals)."""
@@ -51,6 +52,40 @@ def rmat_relabelled_pairs(n, m_undirected, seed, device, perm_seed=3):
     perm = torch.randperm(n, device=device, generator=gen)
     u, v = perm[torch.div(keys, n, rounding_mode="floor")], perm[keys % n]
     return u, v
+
+
+def community_pairs(n, m, seed, device, mix=0.2, gamma=2.5, tau=2.0, size_lo=64, size_hi=65536, max_weight=30000.0):
+    """A community-structured power-law graph (BTER / LFR-like, what citation and co-purchase graphs such as Cora or ogbn-arxiv look
+    like and R-MAT does not): planted communities with power-law SIZES (exponent ``tau``, ``size_lo`` ... ``size_hi`` vertices) x
+    power-law expected DEGREES (Pareto weights, exponent ``gamma``).  Each of the ``m`` undirected pairs picks its source in
+    proportion to the weights and its target, with probability 1 - ``mix``, inside the source's community (again in proportion
+    to the weights), else anywhere.  Vertices are then relabelled by a random permutation, like the bench graph.
+    Returns (u, v, community of every vertex under the FINAL labels)."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    draws = max(1024, int(4 * n / size_lo))
+    sizes = (size_lo * (1.0 - torch.rand(draws, device=device, generator=gen, dtype=torch.float64)).pow(-1.0 / (tau - 1.0))).clamp(max=size_hi).long()
+    ends = torch.cumsum(sizes, 0)
+    ends = ends[: int(torch.searchsorted(ends, torch.tensor([n], device=device))[0]) + 1].clamp(max=n)          # community c = [ends[c-1], ends[c])
+    comm = torch.bucketize(torch.arange(n, device=device), ends, right=True)
+    weight = (1.0 - torch.rand(n, device=device, generator=gen, dtype=torch.float64)).pow(-1.0 / (gamma - 1.0)).clamp(max=max_weight)
+    cdf = torch.cumsum(weight, 0)
+    total = float(cdf[-1])
+    u = torch.searchsorted(cdf, torch.rand(m, device=device, generator=gen, dtype=torch.float64) * total).clamp(max=n - 1)
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), ends[:-1]])
+    c_lo = torch.where(starts > 0, cdf[(starts - 1).clamp(min=0)], torch.zeros_like(cdf[:1]))                    # weight mass before each community
+    c_hi = cdf[ends - 1]
+    cu = comm[u]
+    inside = torch.rand(m, device=device, generator=gen) >= mix
+    lo = torch.where(inside, c_lo[cu], torch.zeros_like(c_lo[:1]))
+    hi = torch.where(inside, c_hi[cu], torch.full_like(c_hi[:1], total))
+    v = torch.searchsorted(cdf, lo + torch.rand(m, device=device, generator=gen, dtype=torch.float64) * (hi - lo)).clamp(max=n - 1)
+    del cdf, weight, lo, hi, inside, cu
+    keep = u != v
+    u, v = u[keep], v[keep]
+    perm = torch.randperm(n, device=device, generator=gen)
+    comm_final = torch.empty_like(comm)
+    comm_final[perm] = comm
+    return perm[u], perm[v], comm_final
 
 
 def rmat_block_entries(n_global, entries_global, seed, device, group=None, grid=None, replicate=False):

@@ -674,12 +674,13 @@ def test_gcn_transform_first(gnntf, golden_dir):
     assert model.graph.last_kernel().split("+")[0] in ("spmm_group16", "spmm_group32")
 
 
-def test_model_level_degree_reorder(gnntf, golden_dir):
-    """GNN(reorder="degree"): same logits (float32 rounding) and the same labels in the caller's node order."""
+@pytest.mark.parametrize("how", ["degree", "locality"])
+def test_model_level_degree_reorder(gnntf, golden_dir, how):
+    """GNN(reorder="degree" / "locality"): same logits (float32 rounding) and the same labels in the caller's node order."""
     from test_oracle_kat import load_cora
     z, coo, vals, shape, X, weights = load_cora(golden_dir)
     logits = []
-    for reorder in (None, "degree"):
+    for reorder in (None, how):
         model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, reorder=reorder)
         for layer, (W, b) in zip([l for l in model.layers() if isinstance(l, gnntf.Dense)], weights):
             layer.W.data.copy_(dev(W)); layer.b.data.copy_(dev(b))
@@ -697,6 +698,48 @@ def test_model_level_degree_reorder(gnntf, golden_dir):
     model.train(train=gnntf.NodeClassification(list(range(300)), labels[:300]), epochs=3, patience=3)
     with pytest.raises(Exception, match="Invalid reorder option"):
         gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, reorder="rcm")
+    # the Cora-shaped stand-in is a random graph: the locality order finds no communities in it and the model says so and keeps
+    # the default order; forced through (threshold 0) it must still give the same logits
+    assert model.reorder_used == ("degree" if how == "degree" else None) and getattr(model.graph, "row_window", 0) == 0
+    if how == "locality":
+        assert 0.0 <= model.locality_share < gnntf.ordering.LOCALITY_MIN_SHARE
+        import unittest.mock
+        with unittest.mock.patch.object(gnntf.ordering, "LOCALITY_MIN_SHARE", 0.0):
+            forced = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, reorder="locality")
+        assert forced.reorder_used == "locality" and forced.graph.row_window == gnntf.ordering.LOCALITY_WINDOW
+        for layer, (W, b) in zip([l for l in forced.layers() if isinstance(l, gnntf.Dense)], weights):
+            layer.W.data.copy_(dev(W)); layer.b.data.copy_(dev(b))
+        forced.training_mode(False)
+        with torch.no_grad():
+            np.testing.assert_allclose(forced(forced.features).cpu().numpy(), logits[0], rtol=1e-5, atol=1e-6)
+
+
+def test_locality_reorder_on_a_graph_with_communities(gnntf):
+    """GNN(reorder="locality") on a planted-partition graph with shuffled labels: the order is taken (communities found), the
+    library runs on row windows, predictions and logits are those of the unordered model."""
+    rng = np.random.default_rng(3)
+    n, k, size = 40000, 100, 400
+    members = rng.permutation(n).reshape(k, size)
+    comm = np.empty(n, dtype=np.int64)
+    for c in range(k):
+        comm[members[c]] = c
+    m = 300000
+    src = rng.integers(n, size=m)
+    dst = np.where(rng.random(m) < 0.85, members[comm[src], rng.integers(size, size=m)], rng.integers(n, size=m))
+    coo = np.concatenate([np.stack([src, dst], 1), np.stack([dst, src], 1)])
+    vals = np.ones(len(coo), dtype=np.float32)
+    X = rng.standard_normal((n, 16)).astype(np.float32)
+    outs = []
+    for reorder in (None, "locality"):
+        gnntf.set_seed(0); torch.manual_seed(0)
+        model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, (n, n)), X, num_classes=40, latent_dims=[], reorder=reorder)
+        model.reset()
+        model.training_mode(False)
+        with torch.no_grad():
+            outs.append(model(model.features))
+    assert model.reorder_used == "locality" and model.locality_share > 0.3 and model.graph.row_window == gnntf.ordering.LOCALITY_WINDOW
+    np.testing.assert_allclose(outs[1].cpu().numpy(), outs[0].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(outs[1].argmax(1), outs[0].argmax(1))
 
 
 @pytest.mark.parametrize("n,entries", [(3000, 30000), (40000, 500000)])

@@ -228,3 +228,29 @@ def test_container_lets_a_layer_take_the_following_ones_along():
     assert [float(l.value[0, 0]) for l in arch.layers()] == [2, 4, 8, 16]
     arch.fuse_runs = False
     assert torch.equal(arch(x), 16 * x) and calls == [3]
+
+
+def test_locality_order_groups_communities():
+    """gnntf.ordering.locality_order (GNN(reorder="locality")): a permutation; on a planted-partition graph with shuffled labels
+    most entries end up between vertices that are close in the new numbering; vertices without entries trail."""
+    from gnntf import ordering
+    rng = np.random.default_rng(0)
+    n, k, size = 6000, 30, 190
+    comm = np.full(n, -1)
+    members = rng.permutation(n)[: k * size].reshape(k, size)                       # 300 vertices stay without entries
+    for c in range(k):
+        comm[members[c]] = c
+    src = members[rng.integers(k, size=60000), rng.integers(size, size=60000)]
+    inside = rng.random(60000) < 0.85
+    dst = np.where(inside, members[comm[src], rng.integers(size, size=60000)], members[rng.integers(k, size=60000), rng.integers(size, size=60000)])
+    idx = torch.from_numpy(np.concatenate([np.stack([src, dst], 1), np.stack([dst, src], 1)]))
+    order = ordering.locality_order(idx, n)
+    assert sorted(order.tolist()) == list(range(n))
+    newid = torch.empty_like(order)
+    newid[order] = torch.arange(n)
+    near = lambda a, b: float(((a - b).abs() < 2 * size).float().mean())
+    assert near(newid[idx[:, 0]], newid[idx[:, 1]]) > 0.5 > 3 * near(idx[:, 0], idx[:, 1])
+    degree = torch.bincount(idx[:, 0], minlength=n)
+    assert bool((degree[order[-(n - k * size):]] == 0).all()) and bool((degree[order[: k * size]] > 0).all())
+    labels = ordering.propagate_labels(idx[:, 0], idx[:, 1], n)
+    assert bool((labels[degree == 0] == torch.arange(n)[degree == 0]).all())          # no neighbours: the own label stays

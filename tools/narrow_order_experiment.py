@@ -29,7 +29,8 @@ import torch
 import bench
 import gnntf
 from gnntf import _native as nat
-from gnntf import sharded
+from gnntf import ordering, sharded
+from gnntf.rmat import community_pairs
 
 INF = 1 << 40
 
@@ -58,54 +59,6 @@ def bfs_positions(src, dst, n, start):
     return pos, levels
 
 
-def community_pairs(n, m, seed, device, mix=0.2, gamma=2.5, tau=2.0, size_lo=64, size_hi=65536, max_weight=30000.0):
-    """A community-structured power-law graph (BTER / LFR-like, what citation and co-purchase graphs such as Cora or ogbn-arxiv look
-    like and R-MAT does not): planted communities with power-law SIZES (exponent ``tau``, ``size_lo`` ... ``size_hi`` vertices) x
-    power-law expected DEGREES (Pareto weights, exponent ``gamma``).  Each of the ``m`` undirected pairs picks its source in
-    proportion to the weights and its target, with probability 1 - ``mix``, inside the source's community (again in proportion
-    to the weights), else anywhere.  Vertices are then relabelled by a random permutation, like the bench graph.
-    Returns (u, v, community of every vertex under the FINAL labels)."""
-    gen = torch.Generator(device=device).manual_seed(seed)
-    draws = max(1024, int(4 * n / size_lo))
-    sizes = (size_lo * (1.0 - torch.rand(draws, device=device, generator=gen, dtype=torch.float64)).pow(-1.0 / (tau - 1.0))).clamp(max=size_hi).long()
-    ends = torch.cumsum(sizes, 0)
-    ends = ends[: int(torch.searchsorted(ends, torch.tensor([n], device=device))[0]) + 1].clamp(max=n)          # community c = [ends[c-1], ends[c])
-    comm = torch.bucketize(torch.arange(n, device=device), ends, right=True)
-    weight = (1.0 - torch.rand(n, device=device, generator=gen, dtype=torch.float64)).pow(-1.0 / (gamma - 1.0)).clamp(max=max_weight)
-    cdf = torch.cumsum(weight, 0)
-    total = float(cdf[-1])
-    u = torch.searchsorted(cdf, torch.rand(m, device=device, generator=gen, dtype=torch.float64) * total).clamp(max=n - 1)
-    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), ends[:-1]])
-    c_lo = torch.where(starts > 0, cdf[(starts - 1).clamp(min=0)], torch.zeros_like(cdf[:1]))                    # weight mass before each community
-    c_hi = cdf[ends - 1]
-    cu = comm[u]
-    inside = torch.rand(m, device=device, generator=gen) >= mix
-    lo = torch.where(inside, c_lo[cu], torch.zeros_like(c_lo[:1]))
-    hi = torch.where(inside, c_hi[cu], torch.full_like(c_hi[:1], total))
-    v = torch.searchsorted(cdf, lo + torch.rand(m, device=device, generator=gen, dtype=torch.float64) * (hi - lo)).clamp(max=n - 1)
-    del cdf, weight, lo, hi, inside, cu
-    keep = u != v
-    u, v = u[keep], v[keep]
-    perm = torch.randperm(n, device=device, generator=gen)
-    comm_final = torch.empty_like(comm)
-    comm_final[perm] = comm
-    return perm[u], perm[v], comm_final
-
-
-def lpa_labels(src, dst, n, rounds=4):
-    """Synchronous label propagation: every vertex takes the label most of its neighbours carry (ties: the larger label), for a few
-    rounds from singleton labels -- a cheap community guess whose only use here is as a sort key."""
-    dev = src.device
-    label = torch.arange(n, device=dev)
-    for _ in range(rounds):
-        pair, counts = torch.unique(dst * n + label[src], return_counts=True)          # (vertex, neighbour label) -> how many neighbours
-        best = torch.zeros(n, dtype=torch.int64, device=dev)
-        best.scatter_reduce_(0, torch.div(pair, n, rounding_mode="floor"), counts * n + pair % n, reduce="amax")
-        label = torch.where(best > 0, best % n, label)
-        del pair, counts, best
-    return label
-
-
 def tail_key(name, u, v, n, deg, comm=None):
     """int64 [n]: the secondary sort key inside a degree bin."""
     dev = u.device
@@ -122,7 +75,7 @@ def tail_key(name, u, v, n, deg, comm=None):
     if name == "planted":                                                # the generator's own communities: the best any locality order can do
         return comm.clone(), {}
     if name == "lpa":
-        label = lpa_labels(src, dst, n)
+        label = ordering.propagate_labels(dst, src, n)
         return label, {"lpa_labels": int(torch.unique(label).numel())}
     if name == "bfs":
         pos, levels = bfs_positions(src, dst, n, int(order[0]))
@@ -170,6 +123,7 @@ def main():
             del k1, order, bin_
         torch.cuda.synchronize(); t_order = time.time() - t0
         uu, vv = (u, v) if newid is None else (newid[u], newid[v])
+        info["share_of_pairs_within_a_window"] = float(((uu - vv).abs() < max(a.window, 1)).float().mean()) if a.window > 0 else None
         idx = torch.cat([torch.stack([uu, vv], 1), torch.stack([vv, uu], 1)])
         g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=dev), (n, n)), device=dev)
         del idx, uu, vv, key
