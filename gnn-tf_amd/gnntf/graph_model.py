@@ -50,8 +50,9 @@ class GNN(Trainable):
         ``"locality"``: community by community (gnntf.ordering.locality_order: label propagation) with the library told so
         (row windows, one window of the numbering per XCD at a time) -- for graphs that HAVE communities, as the reference's
         citation datasets do: -14 ... -26 % per propagation at C = 7 ... 256 on a planted-partition x power-law graph of 10M
-        vertices.  On a graph without communities (R-MAT) the order finds none (``locality_share`` below
-        ordering.LOCALITY_MIN_SHARE) and the model keeps the default order (``reorder_used`` is then None).
+        vertices.  On a graph without communities (R-MAT) the order finds none (``locality_share`` fails
+        ordering.found_communities) and the model keeps the default order (``reorder_used`` is then None); so do graphs of
+        a few windows, which fit the caches in any order.
         Measurements: profiles/NOTES.md round 5."""
         super().__init__(features)
         self._order = self._newid = None
@@ -78,7 +79,7 @@ class GNN(Trainable):
                 if reorder == "locality":
                     # did the order find communities?  On a graph without them (R-MAT) it is a loss against the default: keep that
                     self.locality_share = ordering.share_within(coo.indices, newid, ordering.LOCALITY_WINDOW)
-                    if self.locality_share < ordering.LOCALITY_MIN_SHARE:
+                    if not ordering.found_communities(self.locality_share, n, ordering.LOCALITY_WINDOW):
                         order, reorder = None, None
             self.reorder_used = reorder
             if order is not None:

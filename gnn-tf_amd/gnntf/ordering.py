@@ -13,8 +13,10 @@ from __future__ import annotations
 import torch
 
 LOCALITY_WINDOW = 4096           # rows per window handed to gnx_graph_set_row_window (measured 4096 ... 65536: profiles/NOTES.md round 5)
-LOCALITY_MIN_SHARE = 0.1         # below this share of entries between vertices less than a window apart the order found no communities
-                                 # (community graph: 0.36, R-MAT: 0.002) and the model keeps the default order instead
+LOCALITY_MIN_SHARE = 0.1         # the order is kept when at least this share of the entries lies between vertices less than a window apart
+LOCALITY_MIN_LIFT = 3.0          # ... AND that is at least this many times what a random numbering gives (2 W / n): community graph of
+                                 # 10M vertices 0.36 = 440 x chance, R-MAT 0.002 = 2 x; graphs of fewer than ~6 windows cannot pass -- they
+                                 # fit the caches whatever their order
 
 
 def propagate_labels(rows: torch.Tensor, cols: torch.Tensor, n: int, rounds: int = 4) -> torch.Tensor:
@@ -46,3 +48,9 @@ def share_within(indices: torch.Tensor, newid: torch.Tensor, window: int) -> flo
     if indices.shape[0] == 0:
         return 0.0
     return float(((newid[indices[:, 0]] - newid[indices[:, 1]]).abs() < window).float().mean())
+
+
+def found_communities(share: float, n: int, window: int) -> bool:
+    """Is a numbering with ``share`` of the entries inside a window a locality order worth handing to the library?"""
+    chance = min(1.0, 2.0 * window / max(n, 1))
+    return share >= LOCALITY_MIN_SHARE and share >= LOCALITY_MIN_LIFT * chance

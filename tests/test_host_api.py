@@ -254,3 +254,7 @@ def test_locality_order_groups_communities():
     assert bool((degree[order[-(n - k * size):]] == 0).all()) and bool((degree[order[: k * size]] > 0).all())
     labels = ordering.propagate_labels(idx[:, 0], idx[:, 1], n)
     assert bool((labels[degree == 0] == torch.arange(n)[degree == 0]).all())          # no neighbours: the own label stays
+    # the acceptance rule: a share well above what a random numbering gives, on a graph of more than a few windows
+    assert ordering.found_communities(0.36, 10_000_000, 4096) and not ordering.found_communities(0.002, 10_000_000, 4096)
+    assert not ordering.found_communities(1.0, 2708, 4096) and not ordering.found_communities(0.37, 20_000, 4096)
+    assert ordering.share_within(idx, newid, 2 * size) > 0.5 and ordering.share_within(idx[:0], newid, 10) == 0.0
