@@ -79,7 +79,8 @@ class GNN(Trainable):
                 if reorder == "locality":
                     # did the order find communities?  On a graph without them (R-MAT) it is a loss against the default: keep that
                     self.locality_share = ordering.share_within(coo.indices, newid, ordering.LOCALITY_WINDOW)
-                    if not ordering.found_communities(self.locality_share, n, ordering.LOCALITY_WINDOW):
+                    baseline = ordering.degree_order_share(coo.indices, n, ordering.LOCALITY_WINDOW)
+                    if not ordering.found_communities(self.locality_share, n, ordering.LOCALITY_WINDOW, baseline):
                         order, reorder = None, None
             self.reorder_used = reorder
             if order is not None:

@@ -257,4 +257,6 @@ def test_locality_order_groups_communities():
     # the acceptance rule: a share well above what a random numbering gives, on a graph of more than a few windows
     assert ordering.found_communities(0.36, 10_000_000, 4096) and not ordering.found_communities(0.002, 10_000_000, 4096)
     assert not ordering.found_communities(1.0, 2708, 4096) and not ordering.found_communities(0.37, 20_000, 4096)
+    assert not ordering.found_communities(0.35, 200_000, 4096, baseline_share=0.3)            # hubs close under the degree order too: not communities
+    assert ordering.degree_order_share(idx, n, 2 * size) < 0.5 * ordering.share_within(idx, newid, 2 * size)
     assert ordering.share_within(idx, newid, 2 * size) > 0.5 and ordering.share_within(idx[:0], newid, 10) == 0.0
