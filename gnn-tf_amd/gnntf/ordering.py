@@ -34,14 +34,30 @@ def propagate_labels(rows: torch.Tensor, cols: torch.Tensor, n: int, rounds: int
     return label
 
 
-def locality_order(indices: torch.Tensor, n: int, rounds: int = 4) -> torch.Tensor:
+def coarser_labels(rows: torch.Tensor, cols: torch.Tensor, label: torch.Tensor, rounds: int = 4) -> torch.Tensor:
+    """One level up: the groups of ``label`` become the vertices of the quotient graph (one entry per stored entry between two
+    different groups, multiplicities kept as repeated entries) and label propagation runs on THAT -- groups that exchange many
+    entries merge.  Returns, per original vertex, the label of its group's group."""
+    groups, group_of = torch.unique(label, return_inverse=True)
+    gr, gc = group_of[rows.to(torch.int64)], group_of[cols.to(torch.int64)]
+    cross = gr != gc
+    upper = propagate_labels(gr[cross], gc[cross], int(groups.numel()), rounds)
+    return upper[group_of]
+
+
+def locality_order(indices: torch.Tensor, n: int, rounds: int = 4, levels: int = 1) -> torch.Tensor:
     """new id -> old id.  Vertices with entries first, grouped by their propagated label (groups in ascending label order, inside a
-    group heaviest first, then by old id); vertices without entries last."""
+    group heaviest first, then by old id); with ``levels`` > 1 the groups themselves are grouped by label propagation on the
+    quotient graph, level by level (a large community that the first level leaves in many small groups is put back together);
+    vertices without entries last."""
     rows, cols = indices[:, 0], indices[:, 1]
     degree = torch.bincount(rows, minlength=n)
     label = propagate_labels(rows, cols, n, rounds)
     order = torch.argsort(degree, descending=True, stable=True)                       # by degree ...
     order = order[torch.argsort(label[order], stable=True)]                           # ... inside a label ...
+    for _ in range(levels - 1):                                                       # ... the labels inside their coarser groups ...
+        label = coarser_labels(rows, cols, label, rounds)
+        order = order[torch.argsort(label[order], stable=True)]
     return order[torch.argsort((degree[order] == 0).to(torch.int8), stable=True)]     # ... and the empty rows behind everything
 
 

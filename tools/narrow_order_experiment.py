@@ -74,6 +74,11 @@ def tail_key(name, u, v, n, deg, comm=None):
         return key, {}
     if name == "planted":                                                # the generator's own communities: the best any locality order can do
         return comm.clone(), {}
+    if name in ("lpa2", "lpa3", "lpa4"):                               # multi-level: the order itself is the key
+        order = ordering.locality_order(torch.stack([dst, src], 1), n, levels=int(name[3:]))
+        key = torch.empty_like(order)
+        key[order] = torch.arange(n, device=dev)
+        return key, {}
     if name == "lpa":
         label = ordering.propagate_labels(dst, src, n)
         return label, {"lpa_labels": int(torch.unique(label).numel())}
