@@ -693,8 +693,10 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     # outputs compared in the caller's order; prep = what the reordered model's construction costs beyond the plain one's
     from gnntf.rmat import community_pairs
     u, v, _ = community_pairs(n4, e4 // 2, 1, device)
+    pairs = torch.unique(torch.minimum(u, v) * n4 + torch.maximum(u, v))      # every undirected pair once (no duplicate entries: the
+    u, v = torch.div(pairs, n4, rounding_mode="floor"), pairs % n4             # training launches then draw inside the SpMM)
     cidx = torch.cat([torch.stack([u, v], 1), torch.stack([v, u], 1)])
-    del u, v
+    del u, v, pairs
     ccoo = gnntf.SparseCOO(cidx, torch.ones(cidx.shape[0], device=device), (n4, n4))
     Xc = torch.randn(n4, 16, device=device)
     comm_rec = {"what": "planted-partition x power-law graph (gnntf.rmat.community_pairs: communities of 64 ... 65536 vertices, 20 % of the pairs "
@@ -717,6 +719,18 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
                 ms = median_ms(lambda: cm.run(H0c, first=2), reps=3, warm=1)
             key = "locality" if reorder else "default"
             per[key + "_ms"], per[key + "_build_s"], per[key + "_kernel"] = ms, t_build, cm.graph.last_kernel()
+            if C == 40:       # the same K layers in TRAINING mode (per-iteration edge dropout + renormalisation), forward + backward
+                Ht = H0c.detach().clone().requires_grad_()
+                gout_c = torch.rand_like(Ht)
+                cm.layers()[1].value = Ht
+
+                def train_once():
+                    Ht.grad = None
+                    cm.run(Ht, first=2).backward(gout_c)
+                cm.training_mode(True)
+                per[key + "_training_step_ms"] = median_ms(train_once, reps=3, warm=1)
+                cm.training_mode(False)
+                del Ht, gout_c
             if reorder:
                 per["reorder_used"], per["locality_share"], per["entries"] = cm.reorder_used, cm.locality_share, cm.graph.nnz
             for layer in cm.layers():
@@ -727,6 +741,9 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
         per["argmax_equal_share"] = float((outs[None].argmax(1) == outs["locality"].argmax(1)).float().mean())
         per["time_ratio"] = per["locality_ms"] / per["default_ms"]
         comm_rec["widths"].append(per)
+        if C == 40:
+            flat.update(community_graph_C40_training_step_default_ms=per["default_training_step_ms"],
+                        community_graph_C40_training_step_locality_order_ms=per["locality_training_step_ms"])
         flat.update({f"community_graph_C{C}_default_ms": per["default_ms"], f"community_graph_C{C}_locality_order_ms": per["locality_ms"],
                      f"community_graph_C{C}_locality_prep_s": per["locality_build_s"] - per["default_build_s"]})
         del outs

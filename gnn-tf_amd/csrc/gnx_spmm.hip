@@ -1193,6 +1193,7 @@ int pick_vec(const SpmmArgs &p) {
             const int64_t rows_ = p.n_rows - r0_ < per_launch_ ? p.n_rows - r0_ : per_launch_;                               \
             q_.n_rows = r0_ + rows_;    /* a piece ends where the next begins (padded blocks of the XCD map must not run on) */       \
             unsigned grid_ = blocks_for(rows_, rows_per_block);                                                             \
+            if (q_.xcd_rows > 0 && rows_ < 64 * q_.xcd_rows) q_.xcd_rows = 0;   /* a few windows only: they would not fill 8 XCDs evenly */   \
             if (q_.xcd_rows > 0) {     /* xcd_block: whole chunks, the grid padded to 8 of them */                           \
                 q_.xcd_chunk = (uint32_t)((q_.xcd_rows + (rows_per_block) - 1) / (rows_per_block));                          \
                 const unsigned span_ = 8u * q_.xcd_chunk;                                                                   \
