@@ -1,6 +1,7 @@
 #!/bin/bash
 # Validation of a round in one visit: the -m gpu tests (incl. the fixed fuzz slice and the pinned fuzz case), then the default
-# bench line (with its in-run counter passes and yardsticks).
+# bench line (with its in-run counter passes and yardsticks), then a reduced-size all-auto rehearsal of N = 2 on gloo ranks with a
+# weighted cover in the selection.
 #   gpurun --timeout 1200 -- 'bash tools/gpu_validate_round.sh [outdir]'
 O=${1:-gpurun_out/r5a}
 mkdir -p $O
@@ -9,4 +10,5 @@ tail -4 $O/tests.log; grep "seed 303" $O/tests.log; echo "pytest rc=$rc"
 if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then exit $rc; fi
 timeout -k 10 600 python bench.py --steps 5 --warmup 2 > $O/bench_n1.json 2> $O/bench_n1.err; brc=$?
 echo "bench rc=$brc"; grep "^\[bench" $O/bench_n1.err | tail -16
-[ $rc -eq 0 ] && [ $brc -eq 0 ]
+GNX_REHEARSE_ARGS="--push-weights 0.5" bash tools/rehearse_bench.sh $O 2; rrc=$?
+[ $rc -eq 0 ] && [ $brc -eq 0 ] && [ $rrc -eq 0 ]
