@@ -17,8 +17,10 @@ DROP_SEED = 5                                    # seed of the counter RNG in th
 
 
 def draw_case(rng, case):
-    """All random draws of case number ``case`` (the order of the draws is the seed's contract: a recorded (seed, case) pair
-    names the same inputs for ever)."""
+    """All random draws of case number ``case``.  The order of the draws is the seed's contract: a recorded (seed, case) pair names
+    the same inputs as long as no draw is added -- round 5 added ``window`` (the last draw of a graph case), so pairs recorded in
+    rounds 2-4 name other inputs now; the one miss those rounds produced is kept as a FIXTURE for that reason
+    (tests/golden/fuzz_seed303_case1081.npz, dumped before the change)."""
     kind = case % 8
     s = dict(case=case, kind=kind)
     if kind in (0, 1, 2, 3):
@@ -49,6 +51,7 @@ def draw_case(rng, case):
             s["K"] = int(rng.integers(1, 8))
         elif kind == 3 and nnz:
             s["M"] = (0.5 * np.eye(C) + rng.standard_normal((C, C)) * 0.2).astype(np.float32)
+        s["window"] = int(rng.choice([0, 0, 64, 1000]))       # gnx_graph_set_row_window: another launch order, the same sums
     elif kind in (4, 5) and rng.random() < 0.5:
         # tall inputs in the shapes of the persistent kernels (k_dense_wreg / k_dense_ring / k_wgrad_acc), as aligned column slices of
         # wider matrices with a ragged number of rows; float64 on the device
@@ -106,6 +109,8 @@ def training_loops(s):
     n, idx, vals, p, K, case = s["n"], s["idx"], s["vals"], s["p"], s["K"], s["case"]
     a_ = 0.1
     g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, vals, (n, s["n_cols"])), device="cuda:0")
+    if s.get("window"):
+        g.set_row_window(s["window"])
     D = gnntf.sparse.dropped_degree_scales(g, p, DROP_SEED, case, K)
     adjs = [gnntf.sparse.dropped_adjacency(g, p, DROP_SEED, case + k, D=D[k]) for k in range(K)]
     H0, up = dev(s["H0"]), dev(s["X"])
@@ -151,6 +156,8 @@ def check_case(s):
     if kind in (0, 1, 2, 3):
         n, n_cols, nnz, idx, vals, C, X, H0, sq = (s[k] for k in ("n", "n_cols", "nnz", "idx", "vals", "C", "X", "H0", "sq"))
         g = gnntf.DeviceGraph(gnntf.SparseCOO(idx, vals, (n, n_cols)), device="cuda:0")
+        if s.get("window"):
+            g.set_row_window(s["window"])
         longest = int(np.bincount(idx[:, 0], minlength=n).max()) if nnz else 1
         atol = 2e-4 + 1e-5 * np.sqrt(longest) + 1e-7 * longest                 # float32 sums over a hub row's entries cancel (seed 21, case 2280: 336K terms, |sum| = 110, off by 0.018)
         if kind == 0:

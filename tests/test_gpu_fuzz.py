@@ -5,7 +5,8 @@ The miss (round 4, seed 303, case 1081): the chained backward
 trainable.py:70-78's gradient of K dropped iterations, layered.py:47-50) differed from K un-chained launches by 6.07e-5 relative
 to the ROW's own largest element.  The row in question is one of a C = 1 problem whose terms of size ~1 cancel to 1.1e-3: what it
 carries is the float32 noise of its terms.  The fuzz now scales against at least 1 % of the matrix's largest element; here the
-recorded inputs (tests/golden/fuzz_seed303_case1081.npz = `python tests/fuzz_kernels.py --dump 1081 303 ...`) are judged against
+recorded inputs (tests/golden/fuzz_seed303_case1081.npz, written by `python tests/fuzz_kernels.py --dump 1081 303 ...` at the round-5
+commit that split the fuzz into draw_case / check_case, BEFORE the row-window draw was added to the graph cases) are judged against
 float64 through the oracle's materialised dropped adjacencies, per row, on the scale rounding acts on (the sum of the absolute
 values of the terms): the chained result must be as close to float64 as the step-by-step loop is, or within 8 roundings."""
 import os
@@ -26,8 +27,7 @@ def test_fixed_slice_of_the_fuzz():
 
 
 def test_pinned_fixture_is_the_replayed_case(golden_dir):
-    """The fixture is what the seed draws (the first cases of the seed are compared; the whole replay takes 40 s of host time and
-    is done by --dump)."""
+    """The fixture holds the case the round-4 run reported: kind 1 (training loops), n = 65, C = 1, K = 4, p = 0.9, 1732 unique entries."""
     s = fz.load(os.path.join(golden_dir, "fuzz_seed303_case1081.npz"))
     assert (s["seed"], s["case"], s["kind"], s["n"], s["C"], s["K"], s["p"]) == (303, 1081, 1, 65, 1, 4, 0.9)
     assert s["idx"].shape == (1732, 2) and len(np.unique(s["idx"], axis=0)) == 1732
