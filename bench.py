@@ -739,6 +739,8 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
             torch.cuda.empty_cache()
         per["max_abs_difference_of_the_outputs"] = float((outs[None] - outs["locality"]).abs().max())
         per["argmax_equal_share"] = float((outs[None].argmax(1) == outs["locality"].argmax(1)).float().mean())
+        per["bitwise_equal_share"] = float((outs[None] == outs["locality"]).float().mean())
+        per["mean_abs_output"] = float(outs[None].abs().mean())
         per["time_ratio"] = per["locality_ms"] / per["default_ms"]
         comm_rec["widths"].append(per)
         if C == 40:
