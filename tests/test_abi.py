@@ -50,6 +50,7 @@ def test_argument_errors_do_not_need_a_gpu():
     assert b"negative" in lib.gnx_last_error()
     assert lib.gnx_degree_scale(None, 0, 7, 0, None) == -1
     assert lib.gnx_last_error() == b"Invalid matrix normalization"
+    assert lib.gnx_graph_set_row_window(None, 4096, None) == -1 and b"NULL handle" in lib.gnx_last_error()
     with pytest.raises(Exception, match="Invalid matrix normalization"):
         _native.check(-1)
 
