@@ -48,9 +48,9 @@ def test_argument_errors_do_not_need_a_gpu():
     out = ctypes.c_void_p()
     assert lib.gnx_graph_create_coo(-1, 4, 0, None, None, None, ctypes.byref(out)) == -1
     assert b"negative" in lib.gnx_last_error()
+    assert lib.gnx_graph_set_row_window(None, 4096, None) == -1 and b"NULL handle" in lib.gnx_last_error()
     assert lib.gnx_degree_scale(None, 0, 7, 0, None) == -1
     assert lib.gnx_last_error() == b"Invalid matrix normalization"
-    assert lib.gnx_graph_set_row_window(None, 4096, None) == -1 and b"NULL handle" in lib.gnx_last_error()
     with pytest.raises(Exception, match="Invalid matrix normalization"):
         _native.check(-1)
 
