@@ -1810,6 +1810,23 @@ int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void 
     return GNX_OK;
 }
 
+__global__ void k_probe_xcd(int32_t *__restrict__ out) {
+    if (threadIdx.x == 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        out[blockIdx.x] = (int32_t)(id & 0xf);
+    }
+}
+
+int gnx_probe_block_xcd(int64_t n_blocks, int32_t *d_xcd_out, void *stream) {
+    GNX_CHECK_ARG(n_blocks >= 0 && n_blocks < ((int64_t)1 << 24), "gnx_probe_block_xcd: bad block count");
+    if (n_blocks == 0) return GNX_OK;
+    GNX_CHECK_ARG(d_xcd_out != nullptr, "gnx_probe_block_xcd: NULL output");
+    hipLaunchKernelGGL(k_probe_xcd, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, d_xcd_out);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+}
+
 int gnx_gather_rows(const float *d_X, int64_t ldx, const int64_t *d_idx, int64_t n_idx, int64_t C, float *d_out, int64_t ldo,
                     void *stream) {
     GNX_CHECK_ARG(n_idx >= 0 && C >= 1 && ldx >= C && ldo >= C, "gnx_gather_rows: bad sizes");

@@ -84,6 +84,7 @@ SIGNATURES = {
     "gnx_linear_combination": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "gnx_stream_read": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "gnx_stream_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "gnx_probe_block_xcd": (c_int, [c_int64, c_void_p, c_void_p]),
     "gnx_graph_last_kernel": (c_char_p, [c_void_p]),
 }
 

@@ -379,6 +379,10 @@ int gnx_linear_combination(int k, const float *const *d_src, const float *coef, 
 int gnx_stream_copy(const float *d_src, float *d_dst, int64_t n_floats, void *stream);
 /* The read-only yardstick: streams d_src[0..n) once and folds it into d_sink64 [64 floats] (accumulated, not cleared). */
 int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void *stream);
+/* Measurement aid: launches n_blocks workgroups and writes, per workgroup, the id of the XCD it ran on (HW_REG_XCC_ID, 0..7) to
+ * d_xcd_out [n_blocks].  The row-window launch order (gnx_graph_set_row_window) ASSUMES, for speed only, that the dispatcher deals
+ * workgroups round-robin over the eight XCDs (blocks b and b + 8 share one); tests record here whether the box at hand does. */
+int gnx_probe_block_xcd(int64_t n_blocks, int32_t *d_xcd_out, void *stream);
 
 /* Name of the SpMM kernel the last gnx_spmm/_t call on this handle dispatched (static
  * string; for profiles and tests): "spmm_wave", "spmm_group4" ... "spmm_group32" (lanes per row), "..._drop" (weights made

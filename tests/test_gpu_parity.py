@@ -747,6 +747,21 @@ def test_locality_reorder_on_a_graph_with_communities(gnntf):
     assert plain.reorder_used is None and getattr(plain.graph, "row_window", 0) == 0          # (its hubs are close in ANY degree-aware order)
 
 
+def test_workgroups_are_dealt_round_robin_over_the_xcds(gnntf, capsys):
+    """The speed assumption of the row-window launch order (xcd_block): workgroups b and b + 8 run on the same XCD.  Recorded, and
+    asserted for a grid that fits the chip in one wave of workgroups; results never depend on it."""
+    from gnntf import _native as nat
+    out = torch.full((4096,), -1, dtype=torch.int32, device="cuda:0")
+    nat.check(nat.lib().gnx_probe_block_xcd(4096, nat.ptr(out), nat.current_stream()))
+    xcd = out.cpu().numpy()
+    assert xcd.min() >= 0 and xcd.max() <= 7
+    same = float((xcd[8:] == xcd[:-8]).mean())
+    groups = [sorted(set(xcd[r::8].tolist())) for r in range(8)]
+    with capsys.disabled():
+        print(f"\n[xcd placement] blocks b and b + 8 on the same XCD: {same:.4f} of 4088 pairs; XCDs seen per residue class of blockIdx % 8: {groups}")
+    assert same > 0.99 and len(set(xcd[:8].tolist())) == 8
+
+
 @pytest.mark.parametrize("n,entries", [(3000, 30000), (40000, 500000)])
 def test_row_window_changes_the_launch_order_not_the_sums(gnntf, n, entries):
     """gnx_graph_set_row_window: rows taken in windows of the caller's numbering (degree-binned inside a window).  Every row's sum
