@@ -3,15 +3,16 @@
 # degrees, N = 10M, ~100M entries, randomly relabelled -- tools/narrow_order_experiment.py --graph community)?
 #   part "bins"    (round 5, first visit): the orders INSIDE the library's global degree bins, as round 4 tried on R-MAT
 #   part "windows" the orders handed over as locality orders (gnx_graph_set_row_window): rows taken in windows of the numbering
+#   part "shipped" the default order against what GNN(reorder="locality") does: kernel stats + counter passes at C = 8 and 40
 # Each part times the K = 10 loop at C = 7 / 8 / 40 / 64 and takes FETCH_SIZE / WRITE_SIZE passes at C = 8.
-#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows]'
+#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows|shipped]'
 export TMPDIR=/tmp
 O=${1:-gpurun_out/r5b}
 PART=${2:-windows}
 mkdir -p $O
 T=tools/narrow_order_experiment.py
 
-fetch_pass() {   # LABEL then the tool's arguments: FETCH_SIZE + WRITE_SIZE passes, bytes per launch appended to $O/fetch_C8.jsonl
+fetch_pass() {   # LABEL then the tool's arguments: FETCH_SIZE + WRITE_SIZE passes, bytes per launch appended to $O/fetch.jsonl
   local label=$1; shift
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_${label}_$ctr
@@ -29,11 +30,26 @@ rec = json.loads(open(f"{O}/pmc_{label}_FETCH_SIZE.json").read().strip().splitli
 line = dict(run=label, graph=rec["graph"], order=rec["order"], window=rec.get("window", 0), C=rec["C"], ms_per_K10_under_the_profiler=rec["ms_per_K10"],
             fabric_GB_per_launch=total / 1e9, alg_GB_per_launch=rec["alg_GB_per_launch"], ratio=total / 1e9 / rec["alg_GB_per_launch"])
 print(json.dumps(line))
-open(f"{O}/fetch_C8.jsonl", "a").write(json.dumps(line) + "\n")
+open(f"{O}/fetch.jsonl", "a").write(json.dumps(line) + "\n")
 PY
   find $O/pmc_${label}_* -name "*_counter_collection.csv" -size +30M -delete
 }
 
+if [ "$PART" = "shipped" ]; then
+  # what GNN(reorder="locality") does (label-propagation order, window 4096, one window per XCD chunk) against the default order:
+  # kernel stats + FETCH_SIZE / WRITE_SIZE passes at the widths gnntf's APPNP propagates
+  for C in 8 40; do
+    for spec in "default:--only workload" "locality:--window 4096 --only lpa"; do
+      name=${spec%%:*}; args=${spec#*:}
+      fetch_pass shipped_${name}_C$C --graph community --feats $C $args || exit 1
+      rm -rf $O/stats_${name}_C$C
+      timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_${name}_C$C -o run -- python3 $T --graph community --feats $C $args --rounds 1 \
+          > $O/stats_${name}_C$C.json 2> $O/stats_${name}_C$C.err || { echo "stats $name $C failed"; exit 1; }
+      rm -f $O/stats_${name}_C$C/*kernel_trace.csv
+    done
+  done
+  echo "community experiment (shipped) done"; exit 0
+fi
 if [ "$PART" = "bins" ]; then
   timeout -k 10 400 python3 $T --graph community --feats 7,8,40 > $O/community_timing.jsonl 2> $O/community_timing.err || { echo timing failed; tail -5 $O/community_timing.err; exit 1; }
   cut -c1-260 $O/community_timing.jsonl
