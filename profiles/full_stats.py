@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/r02_full_bench_kernel_stats.csv from a `rocprofv3 --kernel-trace --stats` run of the FULL default bench
-(tools/gpu_profile_full.sh): this repo's kernels only (k_*), torch's own elementwise / sort kernels left out.
+(tools/gpu_profile_set.sh: profile_full): this repo's kernels only (k_*), torch's own elementwise / sort kernels left out.
 
     python profiles/full_stats.py gpurun_out/r2full/stats/run_kernel_stats.csv profiles/r02_full_bench_kernel_stats.csv
 """
