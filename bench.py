@@ -399,7 +399,7 @@ def measure_traffic_in_run(workloads, seconds=240.0, K=10):
 MEASURED_READ_PEAK = [None]        # in-run read-only streaming rate (set once by main)
 
 
-FRAC_LEVEL = "fabric: bytes leaving the L2s, Infinity-Cache hits included -- NOT DRAM bandwidth (dram_frac_* and no_reuse_gather_* are)"
+FRAC_LEVEL = "fabric: bytes leaving the L2s incl. Infinity-Cache hits -- NOT DRAM bandwidth (see dram_frac_*, no_reuse_gather_*)"
 
 
 def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_min=None, what=None):
