@@ -3,7 +3,7 @@ preprocessing step of the graph ingest ("vertex r
 
 ``locality_order``: a numbering in which neighbours in the graph are neighbours in memory, for graphs that HAVE communities
 (citation / co-purchase graphs such as the reference's Cora, Citeseer, Pubmed, ogbn-arxiv: experiments/experiment_setup.py:153-181).
-A few rounds of synchronous label propagation guess the communities; vertices are then numbered community by community.  The
+Ten rounds of synchronous label propagation guess the communities; vertices are then numbered community by community.  The
 library is told so (gnx_graph_set_row_window): it takes the rows in windows of that numbering and gives the workgroups of one XCD
 a contiguous stretch of it, so that each L2 holds the rows of H its own communities gather.  What it gives and where it loses
 (R-MAT has no communities: the degree order of the default is better there) is in profiles/NOTES.md, round 5.
@@ -12,6 +12,9 @@ from __future__ import annotations
 
 import torch
 
+LOCALITY_ROUNDS = 10             # rounds of label propagation (measured on the 10M-vertex community graph, share of entries inside a window /
+                                 # K = 10 loop at C = 8: 1 round 0.05 / 17.9 ms, 2 0.15 / 17.3, 4 0.38 / 15.1, 6 0.50 / 14.4, 10 0.56 / 14.0,
+                                 # 20 0.58 / 13.9; the generator's own communities 0.57 / 14.0; prep 0.08 ... 0.34 s)
 LOCALITY_WINDOW = 4096           # rows per window handed to gnx_graph_set_row_window (measured 4096 ... 65536: profiles/NOTES.md round 5)
 LOCALITY_MIN_SHARE = 0.1         # the order is kept when at least this share of the entries lies between vertices less than a window apart
 LOCALITY_MIN_LIFT = 3.0          # ... AND that is at least this many times what a numbering WITHOUT community knowledge gives: a random one
@@ -21,7 +24,7 @@ LOCALITY_MIN_LIFT = 3.0          # ... AND that is at least this many times what
                                  # fit the caches whatever their order
 
 
-def propagate_labels(rows: torch.Tensor, cols: torch.Tensor, n: int, rounds: int = 4) -> torch.Tensor:
+def propagate_labels(rows: torch.Tensor, cols: torch.Tensor, n: int, rounds: int = LOCALITY_ROUNDS) -> torch.Tensor:
     """Synchronous label propagation over the stored entries (row <- col): every vertex takes the label most of its neighbours
     carry (ties: the larger label), ``rounds`` times from singleton labels.  Vertices without entries keep their own label."""
     label = torch.arange(n, device=rows.device)
@@ -34,7 +37,7 @@ def propagate_labels(rows: torch.Tensor, cols: torch.Tensor, n: int, rounds: int
     return label
 
 
-def coarser_labels(rows: torch.Tensor, cols: torch.Tensor, label: torch.Tensor, rounds: int = 4) -> torch.Tensor:
+def coarser_labels(rows: torch.Tensor, cols: torch.Tensor, label: torch.Tensor, rounds: int = LOCALITY_ROUNDS) -> torch.Tensor:
     """One level up: the groups of ``label`` become the vertices of the quotient graph (one entry per stored entry between two
     different groups, multiplicities kept as repeated entries) and label propagation runs on THAT -- groups that exchange many
     entries merge.  Returns, per original vertex, the label of its group's group."""
@@ -45,7 +48,7 @@ def coarser_labels(rows: torch.Tensor, cols: torch.Tensor, label: torch.Tensor, 
     return upper[group_of]
 
 
-def locality_order(indices: torch.Tensor, n: int, rounds: int = 4, levels: int = 1) -> torch.Tensor:
+def locality_order(indices: torch.Tensor, n: int, rounds: int = LOCALITY_ROUNDS, levels: int = 1) -> torch.Tensor:
     """new id -> old id.  Vertices with entries first, grouped by their propagated label (groups in ascending label order, inside a
     group heaviest first, then by old id); with ``levels`` > 1 the groups themselves are grouped by label propagation on the
     quotient graph, level by level (a large community that the first level leaves in many small groups is put back together);

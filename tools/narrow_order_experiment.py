@@ -79,6 +79,11 @@ def tail_key(name, u, v, n, deg, comm=None):
         key = torch.empty_like(order)
         key[order] = torch.arange(n, device=dev)
         return key, {}
+    if name.startswith("lpa_r"):                                        # label propagation with another number of rounds
+        order = ordering.locality_order(torch.stack([dst, src], 1), n, rounds=int(name[5:]))
+        key = torch.empty_like(order)
+        key[order] = torch.arange(n, device=dev)
+        return key, {}
     if name == "lpa":
         label = ordering.propagate_labels(dst, src, n)
         return label, {"lpa_labels": int(torch.unique(label).numel())}
