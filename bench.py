@@ -345,25 +345,26 @@ def measure_traffic_in_run(workloads, seconds=240.0, K=10):
             cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "run", "--", "python3", os.path.abspath(__file__)] + child_args
             # the pass runs in a process group of its own, so that a pass that outlives its time limit can be ended WHOLE (profiler
             # and the python under it): a survivor would keep tens of GB of the card this process is about to use
+            err_path = os.path.join(tmp, ctr + ".err")
             try:
-                errlog = open(os.path.join(tmp, ctr + ".err"), "w+")
-                child = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=errlog,
-                                         start_new_session=True)
-                try:
-                    rc = child.wait(timeout=max(30.0, seconds - (time.time() - t_start)))
-                except subprocess.TimeoutExpired:
-                    import signal
-                    os.killpg(child.pid, signal.SIGKILL)                  # (its own session: pgid == pid of the process started here)
-                    child.wait()
-                    problem = f"pass {ctr} exceeded its time limit and was ended"
+                with open(err_path, "w") as errlog:
+                    child = subprocess.Popen(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=errlog,
+                                             start_new_session=True)
+                    try:
+                        rc = child.wait(timeout=max(30.0, seconds - (time.time() - t_start)))
+                    except subprocess.TimeoutExpired:
+                        import signal
+                        os.killpg(child.pid, signal.SIGKILL)              # (its own session: pgid == pid of the process started here)
+                        child.wait()
+                        problem = f"pass {ctr} exceeded its time limit and was ended"
+                if problem is not None:
                     break
             except Exception as error:
                 problem = repr(error)[:200]
                 break
             found = glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True)
             if rc != 0 or not found:
-                errlog.seek(0)
-                problem = f"pass {ctr} failed (rc {rc}): " + errlog.read()[-200:]
+                problem = f"pass {ctr} failed (rc {rc}): " + open(err_path).read()[-200:]
                 break
             csvs[ctr] = max(found, key=os.path.getmtime)
         how = "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of `python3 bench.py " + " ".join(child_args) + "`, run by THIS bench process on " \

@@ -171,3 +171,55 @@ def test_fabric_bytes_from_counter_files(tmp_path):
 def test_in_run_entries_take_precedence(monkeypatch):
     monkeypatch.setitem(bench.IN_RUN_TRAFFIC, "rmat_n80000000_nnz1000000000_C128", (1.0e9, "this run"))
     assert bench.pmc_traffic("rmat_n80000000_nnz1000000000_C128") == (1.0e9, "this run")
+
+
+def test_in_run_counter_passes_with_a_stand_in_profiler(tmp_path, monkeypatch):
+    """measure_traffic_in_run's plumbing without a GPU: a stand-in `rocprofv3` on PATH writes the counter file a pass would leave
+    (or fails); the bytes per launch land in IN_RUN_TRAFFIC under the workload's / the segments' names, a failing pass leaves the
+    committed table in charge and says why."""
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    script = fake / "rocprofv3"
+    script.write_text('''#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+ctr, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+child = a[a.index("--") + 1:]
+if os.environ.get("FAKE_PROFILER_FAILS") == ctr:
+    sys.stderr.write("no counter access on this box\\n"); sys.exit(3)
+os.makedirs(os.path.join(out, "host", "1"), exist_ok=True)
+rows, d = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"], 0
+def emit(kernel, value):
+    global d
+    d += 1
+    rows.append(f'{d},"{kernel}",{ctr},{value}')
+if "--pmc-child" in child:                       # the segments process: marker | measured | marker | warm-up | marker | measured ...
+    for i in range(8):
+        emit("k_spmm_group<4, 4, 4, true>", 999)            # warm-up of piece i
+        emit("k_stream<8, false>", 0)
+        for _ in range(10 if i < 6 else 3):
+            emit("k_spmm_group<4, 4, 4, true>", 100 + i)
+        emit("k_stream<8, false>", 0)
+else:
+    for _ in range(20):
+        emit("k_spmm_wave<4, 8, 8>", 50); emit("k_spmm_long_partial<4, 8>", 5); emit("k_spmm_long_reduce<4>", 1)
+open(os.path.join(out, "host", "1", "run_counter_collection.csv"), "w").write("\\n".join(rows) + "\\n")
+''')
+    script.chmod(0o755)
+    monkeypatch.setenv("PATH", str(fake) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setattr(bench, "IN_RUN_TRAFFIC", {})
+    notes = bench.measure_traffic_in_run(["config4", "segments"], seconds=60.0, K=10)
+    assert notes["config4"] == "measured in this run" and notes["segments"] == "measured in this run"
+    plan = bench.segment_plan(10)
+    for i, (name, launches) in enumerate(plan):
+        per_launch = (100 + i) * 2048.0 + (100 + i) * 1024.0                       # FETCH x 2 KiB + WRITE KiB, per launch
+        assert bench.IN_RUN_TRAFFIC[name][0] == pytest.approx(per_launch), name
+    # (the segments pass carries C = 256 too: it overrides the one-command figure of config 4 with its own)
+    rec = bench.roofline_record(10_000_000, 100_000_000, 256, 0.0142, 10, "rmat_n10000000_nnz100000000_C256", 5600.0)
+    assert rec["traffic_in_run"] is True and "THIS bench process" in rec["traffic_source"]
+    # a pass that fails: nothing is claimed for that workload, the note says why
+    monkeypatch.setattr(bench, "IN_RUN_TRAFFIC", {})
+    monkeypatch.setenv("FAKE_PROFILER_FAILS", "WRITE_SIZE")
+    notes = bench.measure_traffic_in_run(["config5"], seconds=60.0)
+    assert notes["config5"].startswith("not measured in this run (pass WRITE_SIZE failed (rc 3)") and "no counter access" in notes["config5"]
+    assert bench.IN_RUN_TRAFFIC == {}
