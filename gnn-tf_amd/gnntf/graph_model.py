@@ -49,7 +49,7 @@ class GNN(Trainable):
         H0/out rows and the hub rows become neighbours in memory).
         ``"locality"``: community by community (gnntf.ordering.locality_order: label propagation) with the library told so
         (row windows, one window of the numbering per XCD at a time) -- for graphs that HAVE communities, as the reference's
-        citation datasets do: -14 ... -26 % per propagation at C = 7 ... 256 on a planted-partition x power-law graph of 10M
+        citation datasets do: -16 ... -31 % per propagation at C = 7 ... 256 on a planted-partition x power-law graph of 10M
         vertices.  On a graph without communities (R-MAT) the order finds none (``locality_share`` fails
         ordering.found_communities) and the model keeps the default order (``reorder_used`` is then None); so do graphs of
         a few windows, which fit the caches in any order.
