@@ -3,9 +3,10 @@
 # degrees, N = 10M, ~100M entries, randomly relabelled -- tools/narrow_order_experiment.py --graph community)?
 #   part "bins"    (round 5, first visit): the orders INSIDE the library's global degree bins, as round 4 tried on R-MAT
 #   part "windows" the orders handed over as locality orders (gnx_graph_set_row_window): rows taken in windows of the numbering
+#   part "window-sweep" window lengths 4096 ... 65,536 of the shipped block map (round 5's locality_window_sweep.sh)
 #   part "shipped" the default order against what GNN(reorder="locality") does: kernel stats + counter passes at C = 8 and 40
 # Each part times the K = 10 loop at C = 7 / 8 / 40 / 64 and takes FETCH_SIZE / WRITE_SIZE passes at C = 8.
-#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows|shipped]'
+#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows|window-sweep|shipped]'
 export TMPDIR=/tmp
 O=${1:-gpurun_out/r5b}
 PART=${2:-windows}
@@ -49,6 +50,20 @@ if [ "$PART" = "shipped" ]; then
     done
   done
   echo "community experiment (shipped) done"; exit 0
+fi
+if [ "$PART" = "window-sweep" ]; then
+  # window length of a locality order (the XCD-aware block map takes one window per chunk), label propagation and planted orders
+  for W in 4096 8192 16384 32768 65536; do
+    timeout -k 10 300 python3 $T --graph community --window $W --feats 7,8,40,64 --only workload,planted,lpa >> $O/window_sweep.jsonl 2>> $O/window_sweep.err || exit 1
+  done
+  timeout -k 10 300 python3 $T --graph community --window 16384 --feats 128,256 --only workload,planted,lpa >> $O/window_sweep.jsonl 2>> $O/window_sweep.err || exit 1
+  timeout -k 10 300 python3 $T --graph rmat --window 16384 --feats 8,40 --only workload,lpa >> $O/window_sweep.jsonl 2>> $O/window_sweep.err || exit 1
+  python3 -c "
+import json
+for l in open('$O/window_sweep.jsonl'):
+    d=json.loads(l); print('  %-9s %-8s w=%-7d C=%-3d %.2f ms' % (d['graph'], d['order'], d['window'], d['C'], d['ms_per_K10']))
+"
+  echo "community experiment (window-sweep) done"; exit 0
 fi
 if [ "$PART" = "bins" ]; then
   timeout -k 10 400 python3 $T --graph community --feats 7,8,40 > $O/community_timing.jsonl 2> $O/community_timing.err || { echo timing failed; tail -5 $O/community_timing.err; exit 1; }
