@@ -446,11 +446,12 @@ def roofline_record(n, nnz, C, launch_s, K, name, measured_peak, b_alg=None, b_m
     return rec
 
 
-def gather_yardstick(device, n, C, a=0.1, d=16):
+def gather_yardstick(device, n, widths, a=0.1, d=16):
     """The no-reuse gather ceiling, measured in this run: one fused SpMM+mix launch over a graph whose every row has ``d`` uniformly
-    random neighbours (tools/regular_sweep.py's graph) at the SAME N and C.  N * C * 4 bytes is far beyond the 256 MB Infinity
-    Cache and no row is gathered more often than any other, so B_alg / t of THIS launch is a DRAM-level rate: what the chip gathers
-    whole random rows at.  R-MAT's figure above it is the hub rows served on-die."""
+    random neighbours (round 4's regular-graph sweep) at the SAME N, for every width of ``widths``.  N * C * 4 bytes is far beyond
+    the caches and no row is gathered more often than any other, so B_alg / t of THIS launch is a DRAM-level rate: what the chip
+    gathers whole random rows at (wide rows), or -- at narrow widths, where a gather moves a 128-byte line for a 32-byte row --
+    what the line granularity leaves of it.  R-MAT's figures above it are the hub rows served on-die.  Returns {C: record}."""
     import torch
     import gnntf
     from gnntf.sparse import _launch
@@ -462,13 +463,17 @@ def gather_yardstick(device, n, C, a=0.1, d=16):
     del idx
     torch.cuda.empty_cache()
     adj = gnntf.Adjacency(g)
-    H, H0 = torch.rand(n, C, device=device), torch.rand(n, C, device=device)
-    out = torch.empty_like(H)
-    ms = median_ms(lambda: _launch(adj, H, H0, 1.0 - a, a, 0, out=out), reps=3, warm=1)
-    rec = {"GBs": alg_bytes_per_iteration(n, g.nnz, C) / ms / 1e6, "launch_ms": ms, "rows": n, "entries": g.nnz, "d": d, "C": C, "kernel": g.last_kernel()}
-    del g, adj, H, H0, out
+    out = {}
+    for C in widths:
+        H, H0 = torch.rand(n, C, device=device), torch.rand(n, C, device=device)
+        res = torch.empty_like(H)
+        ms = median_ms(lambda: _launch(adj, H, H0, 1.0 - a, a, 0, out=res), reps=3, warm=1)
+        out[C] = {"GBs": alg_bytes_per_iteration(n, g.nnz, C) / ms / 1e6, "launch_ms": ms, "rows": n, "entries": g.nnz, "d": d, "C": C,
+                  "kernel": g.last_kernel()}
+        del H, H0, res
+    del g, adj
     torch.cuda.empty_cache()
-    return rec
+    return out
 
 
 def add_gather_ceiling(rec, yard):
@@ -597,10 +602,10 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
     n, nnz = g.n_rows, g.nnz
     widths = []
     flat = {}                                                    # flat scalar copies for the primary line's roofline object (flat_keys)
-    yard = None
+    yards = {}
     if args.gather_yardstick == "on":
-        yard = gather_yardstick(device, n4, c4, a)
-        out["config4_no_reuse_gather_yardstick"] = yard
+        yards = gather_yardstick(device, n4, [w for w in SEGMENT_WIDTHS if not (skip_config4 and w == c4)], a)
+        out["config4_no_reuse_gather_yardstick"] = [yards[w] for w in sorted(yards, reverse=True)]
     for C in ([] if skip_config4 else [c4]) + [w for w in SEGMENT_WIDTHS if w != c4]:
         gen = torch.Generator(device=device).manual_seed(2)
         H0 = torch.rand(n, C, device=device, generator=gen) * 2 - 1
@@ -609,8 +614,8 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False):
                                                                  nat.ptr(work), nat.current_stream())), reps=3, warm=1)
         roof = roofline_record(n, nnz, C, ms * 1e-3 / K, K, workload_name(n4, e4, C), measured_peak)
         rec = {"C": C, "kernel": g.last_kernel(), "ms_per_step": ms, "edges_per_s": nnz * K / ms * 1e3, "roofline": roof}
+        add_gather_ceiling(roof, yards.get(C))
         if C == c4:
-            add_gather_ceiling(roof, yard)
             out["config4_roofline_run"] = dict(rec, workload=workload_name(n4, e4, C) + f"_appnp_K{K}", prep=prep)
             flat.update(flat_keys("config4", roof, ms_per_step=ms, edges_per_s=rec["edges_per_s"]))
             flat.update(config4_workload=workload_name(n4, e4, C) + f"_appnp_K{K}", config4_rows=n, config4_entries=nnz, config4_kernel=rec["kernel"])
@@ -1317,7 +1322,7 @@ def main():
             if args.gather_yardstick == "on":
                 note("no-reuse gather yardstick (d-regular random graph of the same N and C)")
                 t_ph = time.time()
-                yard = gather_yardstick(device, args.nodes, C, a)
+                yard = gather_yardstick(device, args.nodes, [C], a)[C]
                 add_gather_ceiling(roof, yard)
                 result["config"]["no_reuse_gather_yardstick"] = yard
                 phase("gather_yardstick", t_ph)
