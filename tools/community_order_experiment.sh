@@ -4,9 +4,10 @@
 #   part "bins"    (round 5, first visit): the orders INSIDE the library's global degree bins, as round 4 tried on R-MAT
 #   part "windows" the orders handed over as locality orders (gnx_graph_set_row_window): rows taken in windows of the numbering
 #   part "window-sweep" window lengths 4096 ... 65,536 of the shipped block map (round 5's locality_window_sweep.sh)
+#   part "robustness" the shipped configuration at other mixing ratios and at the config-5 size
 #   part "shipped" the default order against what GNN(reorder="locality") does: kernel stats + counter passes at C = 8 and 40
 # Each part times the K = 10 loop at C = 7 / 8 / 40 / 64 and takes FETCH_SIZE / WRITE_SIZE passes at C = 8.
-#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows|window-sweep|shipped]'
+#   gpurun --timeout 1200 -- 'bash tools/community_order_experiment.sh OUTDIR [bins|windows|window-sweep|shipped|robustness]'
 export TMPDIR=/tmp
 O=${1:-gpurun_out/r5b}
 PART=${2:-windows}
@@ -64,6 +65,22 @@ for l in open('$O/window_sweep.jsonl'):
     d=json.loads(l); print('  %-9s %-8s w=%-7d C=%-3d %.2f ms' % (d['graph'], d['order'], d['window'], d['C'], d['ms_per_K10']))
 "
   echo "community experiment (window-sweep) done"; exit 0
+fi
+if [ "$PART" = "robustness" ]; then
+  # how the shipped configuration behaves away from the graph it was tuned on: more pairs leaving their community (mix 0.4 / 0.6),
+  # and the config-5 size (80M vertices / ~1B entries, C = 128)
+  for MIX in 0.4 0.6; do
+    timeout -k 10 300 python3 $T --graph community --mix $MIX --window 4096 --feats 8,40 --only workload,lpa,planted > $O/robust_mix$MIX.jsonl 2> $O/robust_mix$MIX.err || { echo "mix $MIX failed"; exit 1; }
+  done
+  timeout -k 10 800 python3 $T --graph community --nodes 80000000 --entries 1000000000 --window 4096 --feats 128 --only workload,lpa --rounds 2 \
+      > $O/robust_80M_C128.jsonl 2> $O/robust_80M_C128.err || { echo "80M failed"; tail -3 $O/robust_80M_C128.err; exit 1; }
+  python3 -c "
+import json, glob
+for f in sorted(glob.glob('$O/robust_*.jsonl')):
+    for l in open(f):
+        d=json.loads(l); print('  %-26s %-8s C=%-3d %.2f ms  share %s  order %.2f s' % (f.split('/')[-1], d['order'], d['C'], d['ms_per_K10'], d.get('share_of_pairs_within_a_window'), d['order_seconds']))
+"
+  echo "community experiment (robustness) done"; exit 0
 fi
 if [ "$PART" = "bins" ]; then
   timeout -k 10 400 python3 $T --graph community --feats 7,8,40 > $O/community_timing.jsonl 2> $O/community_timing.err || { echo timing failed; tail -5 $O/community_timing.err; exit 1; }
