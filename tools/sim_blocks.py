@@ -182,6 +182,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--graph", choices=["rmat", "community"], default="rmat", help="rmat: the bench graph (config 5); community: planted partition x power-law degrees")
+    ap.add_argument("--locality", action="store_true", help="community graph: renumber the vertices by gnntf.ordering.locality_order before cutting the blocks")
     ap.add_argument("--nodes", type=int, default=80_000_000)
     ap.add_argument("--entries", type=int, default=1_000_000_000)
     ap.add_argument("--feats", type=int, default=128)
@@ -214,7 +216,24 @@ def main():
     gnntf.set_default_device(dev)
     P, r, N = a.world, a.rank, a.nodes
     t0 = time.time()
-    u, w = sharded.rmat_relabelled_pairs(N, a.entries // 2, seed=1, device=dev)
+    if a.graph == "community":
+        # a graph WITH communities (gnntf.rmat.community_pairs, every pair once) -- and, with --locality, its vertices renumbered
+        # community by community (gnntf.ordering.locality_order) BEFORE the cut into contiguous blocks: what the exchange of such a
+        # graph would be under the order GNN(reorder="locality") computes
+        from gnntf import ordering
+        from gnntf.rmat import community_pairs
+        u, w, _ = community_pairs(N, a.entries // 2, 1, dev)
+        keys = torch.unique(torch.minimum(u, w) * N + torch.maximum(u, w))
+        u, w = torch.div(keys, N, rounding_mode="floor"), keys % N
+        del keys
+        if a.locality:
+            order = ordering.locality_order(torch.cat([torch.stack([u, w], 1), torch.stack([w, u], 1)]), N)
+            newid = torch.empty_like(order)
+            newid[order] = torch.arange(N, device=dev)
+            u, w = newid[u], newid[w]
+            del order, newid
+    else:
+        u, w = sharded.rmat_relabelled_pairs(N, a.entries // 2, seed=1, device=dev)
     degrees = (torch.bincount(u, minlength=N) + torch.bincount(w, minlength=N)).float()
     bounds = sharded.uniform_bounds(N, P)
     lo, hi = bounds[r], bounds[r + 1]
@@ -285,7 +304,7 @@ def main():
     t_step = (time.time() - t0) / 3
     st = sg.stats
     halo_rows = st["pull_rows"] + st["push_rows"]
-    out = {"world": P, "rank": r, "graph": {"nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
+    out = {"world": P, "rank": r, "graph": {"kind": a.graph, "locality_order": bool(a.locality), "nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
            "split_rows": bool(sg.split_rows), "early_pull": a.early_pull, "transport": a.transport, "lane_skip": a.lane_skip}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
            "local_entries": sg.nnz_local, "push_graph_entries": (sg.push_graph.nnz if sg.push_graph is not None else 0), "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
            "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
