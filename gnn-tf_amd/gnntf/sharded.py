@@ -583,11 +583,14 @@ class ShardedGraph:
 
     def __init__(self, idx_global, vals, bounds, backend=None, group=None, normalized="symmetric", comm=None,
                  relabel=False, cover="cover", split_rows=True, chunks=2, keep_entries=False, edge_dropout=False, early_pull=False,
-                 tune_overlap=True, push_weight=0.0):
+                 tune_overlap=True, push_weight=0.0, row_window=0):
         """``idx_global``: int64 [nnz, 2] (global row, global col) of the entries whose row this rank owns
         (unsorted, duplicates allowed); ``bounds``: the P+1 partition boundaries.  Collective: every rank of the
         vertex partition (``comm`` / ``group``) must call it with the same options.
         ``cover``: "cover" (pull/push vertex cover, default) or "pull" (classic halo; bitwise the one-GPU sums).
+        ``row_window``: the GLOBAL numbering is a locality order (communities contiguous: gnntf.ordering.locality_order applied before
+        the cut into blocks) -- the block's handles then take their rows in windows of this many consecutive local ids
+        (gnx_graph_set_row_window: one window per XCD at a time).  Same sums; only for graphs that have communities.
         ``push_weight`` (cover plans): what a pushed row's entries on the sender weigh against a row on the link
         (cover_push_mask; 0 = fewest rows on the link, larger = fewer and shorter partial sums, more pulled rows).
         ``split_rows``: interior rows (no remote column) as a handle of their own, computed before the halo is
@@ -623,6 +626,7 @@ class ShardedGraph:
         N = self.bounds[-1]
         self.lo, self.hi, self.n_global, self.n_local = lo, hi, N, hi - lo
         self.cover, self.chunks, self.early_pull = cover, max(1, int(chunks)), bool(early_pull)
+        self.row_window = int(row_window)
         self.push_weight = float(push_weight) if cover == "cover" else 0.0
         if self.push_weight < 0:
             raise Exception("ShardedGraph: push_weight must not be negative")
@@ -843,6 +847,10 @@ class ShardedGraph:
         else:
             self.graph = be.graph_from_coo(torch.stack([m_rows, m_cols], 1), m_vals, (n_local, self.n_buf))
             self.graph_int, self.rows_bnd, self.rows_int = None, None, None
+        if self.row_window > 0:                                # the caller's numbering carries locality: row windows on the block's handles
+            for handle in (self.graph, self.graph_int):
+                if handle is not None and hasattr(handle, "set_row_window"):
+                    handle.set_row_window(self.row_window)
         if self.edge_dropout:                                  # dropout draws keyed by the GLOBAL (row, col) of every entry
             gid = torch.empty(self.n_buf, dtype=torch.int32, device=dev)
             gid[halo_col] = halo.to(torch.int32)

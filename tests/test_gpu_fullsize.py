@@ -188,16 +188,21 @@ def test_pull_plan_keeps_the_one_gpu_summation_order_bitwise(gnntf):
     H0 = torch.rand(n, C, device=device, generator=torch.Generator(device=device).manual_seed(2)) * 2 - 1
     bounds = sharded.uniform_bounds(n, world)
 
-    def rank_body(comm):
+    def rank_body(comm, row_window=0):
         lo, hi = bounds[comm.rank], bounds[comm.rank + 1]
         mu, mw = (u >= lo) & (u < hi), (w >= lo) & (w < hi)
         idx = torch.cat([torch.stack([u[mu], w[mu]], 1), torch.stack([w[mw], u[mw]], 1)])
-        sg = sharded.ShardedGraph(idx, torch.ones(idx.shape[0], device=device), bounds, comm=comm, cover="pull", chunks=2)
+        sg = sharded.ShardedGraph(idx, torch.ones(idx.shape[0], device=device), bounds, comm=comm, cover="pull", chunks=2, row_window=row_window)
+        assert getattr(sg.graph, "row_window", 0) == row_window
         state = sg.make_state(H0[lo:hi])
         assert [c1 - c0 for c0, c1 in state.cols] == [64, 64]
         return sg.propagate(state, 0.1, 10).clone()
 
     got = torch.cat(run_ranks(world, rank_body))
+    # the same blocks on row windows (ShardedGraph(row_window=): the launch order of a locality numbering, one window per XCD chunk):
+    # another order of the launches, the same sums
+    windowed = torch.cat(run_ranks(world, lambda comm: rank_body(comm, 4096)))
+    assert torch.equal(windowed, got)
     idx = torch.cat([torch.stack([u, w], 1), torch.stack([w, u], 1)])
     whole = gnntf.normalize(gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=device), (n, n)), device=device), "symmetric")
     del idx

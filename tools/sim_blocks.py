@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--graph", choices=["rmat", "community"], default="rmat", help="rmat: the bench graph (config 5); community: planted partition x power-law degrees")
+    ap.add_argument("--row-window", type=int, default=0, help="with --locality: the block's handles take their rows in windows of this many ids (ShardedGraph(row_window=))")
     ap.add_argument("--locality", action="store_true", help="community graph: renumber the vertices by gnntf.ordering.locality_order before cutting the blocks")
     ap.add_argument("--nodes", type=int, default=80_000_000)
     ap.add_argument("--entries", type=int, default=1_000_000_000)
@@ -252,7 +253,7 @@ def main():
         comm.spin_per_s = spin_rate()
     _skipped = [torch.cuda.Stream(dev) for _ in range(a.lane_skip)]
     sg = SimGraph(idx, vals, bounds, comm=comm, cover=a.cover, chunks=a.chunks, split_rows=not a.whole_rows, keep_entries=True,
-                  push_weight=a.push_weight)
+                  push_weight=a.push_weight, row_window=a.row_window)
     sg.entries = None
     del idx, vals, comm.mirrored
     torch.cuda.synchronize()
@@ -304,7 +305,7 @@ def main():
     t_step = (time.time() - t0) / 3
     st = sg.stats
     halo_rows = st["pull_rows"] + st["push_rows"]
-    out = {"world": P, "rank": r, "graph": {"kind": a.graph, "locality_order": bool(a.locality), "nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
+    out = {"world": P, "rank": r, "graph": {"kind": a.graph, "locality_order": bool(a.locality), "row_window": a.row_window, "nodes": N, "entries": a.entries, "features": C}, "options": {"cover": a.cover, "chunks": a.chunks,
            "split_rows": bool(sg.split_rows), "early_pull": a.early_pull, "transport": a.transport, "lane_skip": a.lane_skip}, "gen_s": round(t_gen, 2), "plan_s": round(t_plan, 2), "stats": st,
            "local_entries": sg.nnz_local, "push_graph_entries": (sg.push_graph.nnz if sg.push_graph is not None else 0), "halo_rows": halo_rows, "halo_bytes_per_iteration": halo_rows * C * 4,
            "pull_only_bytes_per_iteration": st["pull_only_rows"] * C * 4, "kernels_ms_per_iteration": t_c * 1e3,
