@@ -25,7 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gnn-tf_amd")]
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-PUSH_WEIGHTS_DEFAULT = ""           # weighted covers the N > 1 selection times beside "cover" and "pull" (the table over w)
+PUSH_WEIGHTS_DEFAULT = "0.5"        # weighted covers the N > 1 selection times beside "cover" and "pull" (under EMULATED link time
+                                    # w = 0 wins at every rate; one intermediate weight is timed anyway, inside the selection's wall-clock budget,
+                                    # because what real xGMI links do beside the kernels is exactly what no one-GPU rehearsal can show)
 WORKLOADS = {"config5": (80_000_000, 1_000_000_000, 128),       # BASELINE.json configs[4]: the scaling graph (default)
              "config4": (10_000_000, 100_000_000, 256)}          # BASELINE.json configs[3]: the roofline run
 
