@@ -123,11 +123,13 @@ def test_captured_training_equals_eager(gnntf):
     for eager, captured in zip(results[0][:-1], results[1][:-1]):
         np.testing.assert_allclose(captured, eager, rtol=2e-3, atol=2e-5)
     # the reference model with all its dropouts: trains, predicts, and a sampler-driven task is refused with a clear message
-    gnntf.set_seed(0)
-    appnp = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=4, fused=True)
-    appnp.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
-                epochs=20, patience=20, capture=True)
-    assert appnp.predict(gnntf.NodeClassification(list(range(400, 800)))).shape[0] == 400 and not appnp.is_training()
+    for fused in (False, True):                   # the reference's layer list (fused at execution) and the collapsed PPRLoop layer
+        gnntf.set_seed(0)
+        appnp = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=4, fused=fused)
+        appnp.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
+                    epochs=20, patience=20, capture=True)
+        assert appnp.predict(gnntf.NodeClassification(list(range(400, 800)))).shape[0] == 400 and not appnp.is_training()
+        assert len(appnp.layers()) == (5 if fused else 13)
     # a task that draws new edges on the host at every call cannot be replayed: refused with a clear message, nothing left behind
     import networkx as nx
     G = nx.Graph(); G.add_nodes_from(range(800)); G.add_edges_from((int(u), int(v)) for u, v in coo if u < v)
