@@ -129,7 +129,7 @@ def test_captured_training_equals_eager(gnntf):
         appnp.train(train=gnntf.NodeClassification(train, labels[train]), valid=gnntf.NodeClassification(valid, labels[valid]),
                     epochs=20, patience=20, capture=True)
         assert appnp.predict(gnntf.NodeClassification(list(range(400, 800)))).shape[0] == 400 and not appnp.is_training()
-        assert len(appnp.layers()) == (5 if fused else 13)
+        assert len(appnp.layers()) == (4 if fused else 13)
     # a task that draws new edges on the host at every call cannot be replayed: refused with a clear message, nothing left behind
     import networkx as nx
     G = nx.Graph(); G.add_nodes_from(range(800)); G.add_edges_from((int(u), int(v)) for u, v in coo if u < v)
