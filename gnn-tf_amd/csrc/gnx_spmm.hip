@@ -381,7 +381,7 @@ __device__ __forceinline__ void group_rows_coop(const SpmmArgs &p, int64_t block
 
 template <int VEC, int G, int U, bool PIPE>
 __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs p) {
-    if (G <= 8 && !(p.tune & 32768)) group_rows_coop<VEC, G, 4>(p, xcd_block(p));     // (tune bit: tuning builds' A/B switch back to the per-lane fetch)
+    if (G <= 8) group_rows_coop<VEC, G, 4>(p, xcd_block(p));
     else group_rows<VEC, G, U, PIPE>(p, xcd_block(p));
 }
 
@@ -486,292 +486,6 @@ __global__ __launch_bounds__(64 * WPB) void k_spmm_gcnii(const SpmmArgs p, const
         vstore<4>(p.out + rows[ps] * p.ldo + c, o);
     }
 }
-
-// ---- (tuning builds only) GCNII layer at C = 128 in one launch: M in REGISTERS, the neighbour rows gathered by LDS-DMA -----------------
-// An experiment that is CORRECT and SLOWER than the two launches it was meant to replace (config-4 graph: 13.2 ms against 11.2 ms for
-// SpMM+mix followed by the dense kernel; profiles/NOTES.md has the counters): with one wave per SIMD every instruction of the SpMM half
-// is issued by that one wave, and the bookkeeping of a stream that crosses row boundaries costs ~30 instructions per entry where the
-// row kernels spend ~6.  Kept compiled into the tuning library (GNX_GCNII_DMA=1) with tools/gcnii_dma_check.py as its test.
-#ifdef GNX_TUNING
-// The block-shared-M kernel above does not fit C = 128 with enough waves to keep its gathers fed.  Here M (128 x 128 = 256 fragments
-// per lane) lives in the accumulation registers of every wave, one wave per SIMD, as in k_dense_wreg; what makes a single wave per SIMD
-// viable for the SpMM half is that the gathers need no registers: a wave walks its OWN contiguous range of rows as one stream of
-// entries, in batches of GD_B, and fetches the neighbour rows of the batches ahead (512 bytes each, two per instruction) straight into
-// an LDS ring with global_load_lds while it adds up the oldest one -- three batches in flight behind a counted s_waitcnt vmcnt.  Nothing
-// the wave waits for ever passes through a register: the column indices and values of the stream arrive by LDS-DMA as well (64-entry
-// chunks, two chunks ahead), and so do the H0 rows and the row pointers of the next tile (one tile ahead).  Lanes 0-31 add the even
-// entries of a batch, lanes 32-63 the odd ones (a row's sum is the two halves added when the row ends; a pair of entries that straddles
-// two rows ends the first row between its halves).  Finished rows are mixed with H0 in the wave's 16 x 128 LDS tile; when the tile's
-// sixteenth row is done the tile goes through 256 MFMAs against the registers and leaves as whole rows -- the mixed rows never touch
-// HBM (unless the training path asks for them).  Rows longer than p.long_row are stepped over (the stream is cut into segments around
-// them; the long-row kernels and the dense kernel produce them afterwards).
-constexpr int GD_B = 10;                       // entries per batch (five LDS-DMA instructions)
-constexpr int GD_NBUF = 4;                     // ring of batch buffers: one being added up, three in flight
-constexpr int GD_BUF = GD_B * 128;             // floats per batch buffer
-constexpr int GD_LDS_WORDS = GD_NBUF * GD_BUF + 2048 + 2048 + 512 + 128;      // + tile, staged H0 tile, index ring (cols | vals), row pointers x 2
-
-template <bool RELU, bool KEEP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_gcnii_dma(const SpmmArgs p, const float *__restrict__ M, int64_t ldm, float *__restrict__ mixed, uint32_t tiles_per_wave, int64_t nnz) {
-    constexpr int C = 128;
-    extern __shared__ float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int c = lane & 15, g = lane >> 4, half = lane >> 5, hl = lane & 31;
-    float *__restrict__ bufs = lds + wave * GD_LDS_WORDS;
-    float *__restrict__ T = bufs + GD_NBUF * GD_BUF;               // the tile: H0 rows, replaced row by row by the mixed rows
-    float *__restrict__ Hs = T + 2048;                            // the NEXT tile's H0 rows
-    int *__restrict__ colring = reinterpret_cast<int *>(Hs + 2048);     // 4 chunks of 64 column indices
-    float *__restrict__ valring = reinterpret_cast<float *>(colring + 256);
-    int *__restrict__ rp32 = colring + 512;                       // 2 x 64 words: row pointers (int64 as word pairs) of the current and the next tile
-    const uint32_t n = (uint32_t)p.n_rows, n_tiles = (n + 15) / 16;
-    const uint32_t wid = blockIdx.x * 4 + wave;
-    const uint32_t t0 = wid * tiles_per_wave;
-    if (t0 >= n_tiles) return;                                    // (whole waves; no barrier in this kernel)
-    const uint32_t t1 = t0 + tiles_per_wave < n_tiles ? t0 + tiles_per_wave : n_tiles;
-    const uint32_t r0 = t0 * 16, r1 = t1 * 16 < n ? t1 * 16 : n;
-    // M fragments (the MFMA's A operand): mreg[kc][T][t][nt] = M[64 kc + 16 T + 4 g + t][16 nt + c]
-    float mreg[2][4][4][8];
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-        for (int TT = 0; TT < 4; ++TT)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    mreg[kc][TT][t][nt] = M[(int64_t)(64 * kc + 16 * TT + 4 * g + t) * ldm + 16 * nt + c];
-                    asm volatile("" : "+a"(mreg[kc][TT][t][nt]));
-                }
-    const char *__restrict__ Xb = reinterpret_cast<const char *>(p.X);
-    const char *__restrict__ Hb = reinterpret_cast<const char *>(p.H0);
-    const uint32_t x_pitch = (uint32_t)p.ldx * 4u, h_pitch = (uint32_t)p.ldh0 * 4u, o_pitch = (uint32_t)p.ldo * 4u;
-
-    // ---- the stream: entries of rows [r0, r1) in segments between long rows; positions are relative to the range's first entry ----------
-    const int64_t base = p.rowptr[r0];
-    const uint32_t base_lo = (uint32_t)base;
-    const uint32_t s_end = (uint32_t)(p.rowptr[r1] - base);
-    uint32_t seg_beg = 0, seg_end = 0;
-    int64_t li = 0;
-    uint32_t l_beg = UINT32_MAX, l_end = 0;                       // cursor in the (ascending) list of long rows: positions [l_beg, l_end) are not ours
-    {
-        int64_t lo = 0, hi = p.n_long;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((uint32_t)p.long_rows[mid] < r0) lo = mid + 1; else hi = mid;
-        }
-        li = lo;
-    }
-    auto load_long = [&]() {
-        l_beg = UINT32_MAX;
-        if (li < p.n_long) {
-            const uint32_t lr = (uint32_t)p.long_rows[li];
-            if (lr < r1) { l_beg = (uint32_t)(p.rowptr[lr] - base); l_end = (uint32_t)(p.rowptr[lr + 1] - base); }
-        }
-    };
-    load_long();
-    auto open_segment = [&]() -> bool {                           // seg_beg is where the stream stands; skips long rows; false: stream over
-        while (seg_beg == l_beg) { seg_beg = l_end; ++li; load_long(); }
-        if (seg_beg >= s_end) return false;
-        seg_end = l_beg < s_end ? l_beg : s_end;
-        return true;
-    };
-    // index chunks: chunk k = entries [64 k, 64 k + 64) of the matrix, in ring slot k & 3 -- entry e sits at ring word e & 255
-    auto load_chunk = [&](int64_t k) {
-        int64_t e = 64 * k + lane;
-        e = e < nnz ? e : nnz - 1;
-        const int slot = (int)(k & 3);
-        __builtin_amdgcn_global_load_lds(p.colidx + e, colring + slot * 64, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(p.vals + e, valring + slot * 64, 4, 0, 0);
-    };
-    // ---- tiles: H0 rows (slot s of row r holds piece s ^ r: the fragment reads are conflict-free) and row pointers, by LDS-DMA ----------
-    auto stage_rows = [&](uint32_t first_row, float *dst) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t rl = 2 * i + half;
-            uint32_t row = first_row + rl;
-            row = row < n ? row : n - 1;
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(Hb + (uint64_t)row * h_pitch + 16u * (hl ^ rl)), dst + i * 256, 16, 0, 0);
-        }
-    };
-    auto stage_rowptr = [&](uint32_t first_row, int which) {      // word 2 i <- low half of rowptr[first_row + i], i = 0 .. 17 (clamped)
-        uint32_t w = 2 * first_row + (lane < 36 ? lane : 35);
-        w = w < 2 * n + 2 ? w : 2 * n;
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const int *>(p.rowptr) + w, rp32 + which * 64, 4, 0, 0);
-    };
-    uint32_t tile_r0 = r0;
-    int rp_cur = 0;
-    uint32_t r = r0, dead_mask = 0;
-    uint32_t rend = 0, rend_after = 0;                             // end of row r, end of row r + 1 (read one row ahead), as stream positions
-    bool dead = false, entered = false;
-    auto row_end_word = [&](int rl) -> uint32_t { return (uint32_t)rp32[rp_cur * 64 + 2 * (rl + 1)] - base_lo; };
-    auto enter_row = [&](bool primed) {                                            // r is a row of the current tile
-        const int rl = (int)(r - tile_r0);
-        const uint32_t rbeg = primed ? rend : (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)rp32[rp_cur * 64 + 2 * rl] - base_lo));
-        rend = (uint32_t)__builtin_amdgcn_readfirstlane((int)(primed ? rend_after : row_end_word(rl)));      // (primed: read from LDS a row ago)
-        rend_after = row_end_word(rl + 1);                                         // stays in a vector register until the next row (rl + 1 = 16: staged, not used)
-        dead = rend - rbeg > (uint32_t)p.long_row;
-        if (dead) dead_mask |= 1u << rl;
-    };
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    int since_switch = 0;                                                          // batch waits since the last tile switch (its DMAs have landed after three)
-    auto tile_through_m = [&]() {                                                  // the tile's rows are final: out rows = act(tile . M)
-        f32x4 afrag[2][4];
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-            for (int TT = 0; TT < 4; ++TT) afrag[kc][TT] = *reinterpret_cast<const f32x4 *>(T + c * C + 4 * ((16 * kc + 4 * TT + g) ^ c));
-        const bool more = tile_r0 + 16 < r1;
-        if (more) {
-            // the next tile's H0 rows and row pointers were requested a tile ago; a short tile may not have waited enough for them since
-            if (since_switch < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (the tile is in registers)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4 *>(T + i * 256 + lane * 4) = *reinterpret_cast<const f32x4 *>(Hs + i * 256 + lane * 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // Hs has been read: it can take the tile after the next
-            if (tile_r0 + 32 < r1) {
-                stage_rows(tile_r0 + 32, Hs);
-                stage_rowptr(tile_r0 + 32, rp_cur);                                // (the slot of the tile that just ended)
-            }
-        }
-        since_switch = 0;
-        f32x4 d[8];
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) d[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-            for (int TT = 0; TT < 4; ++TT)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < 8; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(mreg[kc][TT][t][nt], afrag[kc][TT][t], d[nt], 0, 0, 0);
-        // D with M as the A operand: lane (c, g), register i -> row c, column 16 nt + 4 g + i
-        const uint32_t row = tile_r0 + c;
-        if (row < r1 && !((dead_mask >> c) & 1u)) {
-            char *o = reinterpret_cast<char *>(p.out) + (uint64_t)row * o_pitch + 16u * g;
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                f32x4 v = d[nt];
-                if constexpr (RELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                *reinterpret_cast<f32x4 *>(o + 64 * nt) = v;
-            }
-        }
-        tile_r0 += 16;
-        rp_cur ^= 1;
-        dead_mask = 0;
-    };
-    auto finish_row = [&]() {                                                      // row r ends here: mix it into the tile, move on
-        if (!dead) {
-            const int rl = (int)(r - tile_r0);
-            float *slot = T + rl * C + 4 * (hl ^ rl);
-            const f32x4 h0 = *reinterpret_cast<const f32x4 *>(slot);
-            f32x4 tot;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tot[i] = acc[i] + __shfl_xor(acc[i], 32);
-            if (half == 0) {
-                f32x4 t;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = fmaf(tot[i], p.beta, h0[i] * p.alpha);       // filter.py:20-21 / gcn.py:25
-                *reinterpret_cast<f32x4 *>(slot) = t;
-                if constexpr (KEEP) *reinterpret_cast<f32x4 *>(mixed + (uint64_t)r * C + 4 * hl) = t;
-            }
-        }
-        acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        ++r;
-        bool primed = true;
-        if (r == r1 || r - tile_r0 == 16) { tile_through_m(); primed = false; }
-        if (r < r1) enter_row(primed);
-    };
-    // ---- batches ---------------------------------------------------------------------------------------------------------------------
-    auto issue_batch = [&](uint32_t pos, int slot) {                               // entries pos .. pos + GD_B - 1 (past the segment: indices that exist, not used)
-        float *buf = bufs + slot * GD_BUF;
-        uint32_t mine[GD_B / 2];
-#pragma unroll
-        for (int q = 0; q < GD_B / 2; ++q) mine[q] = (uint32_t)colring[(base_lo + pos + 2 * q + half) & 255u];
-#pragma unroll
-        for (int q = 0; q < GD_B / 2; ++q)
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(Xb + (uint64_t)mine[q] * x_pitch + 16u * hl), buf + q * 256, 16, 0, 0);
-    };
-    auto add_batch = [&](uint32_t pos, int cnt, int slot) {
-        const float *buf = bufs + slot * GD_BUF + lane * 4;
-        f32x4 x[GD_B / 2];
-        float v[GD_B / 2];
-#pragma unroll
-        for (int q = 0; q < GD_B / 2; ++q) {
-            x[q] = *reinterpret_cast<const f32x4 *>(buf + q * 256);
-            v[q] = valring[(base_lo + pos + 2 * q + half) & 255u];
-        }
-#pragma unroll
-        for (int q = 0; q < GD_B / 2; ++q) {
-            if (2 * q < cnt) {
-                const uint32_t e0 = pos + 2 * q;
-                const int pair = 2 * q + 1 < cnt ? 2 : 1;
-                if (pair == 2 && e0 + 1 < rend) {                                  // both entries of the pair in the row that is open
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(v[q], x[q][i], acc[i]);
-                } else {
-                    for (int sidx = 0; sidx < pair; ++sidx) {                      // one entry at a time: rows end between them
-                        while (e0 + sidx >= rend) finish_row();                    // (rows without entries end here too)
-                        if (half == sidx) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i] = fmaf(v[q], x[q][i], acc[i]);
-                        }
-                    }
-                }
-            }
-        }
-    };
-
-    // ---- prologue: the first two tiles' H0 rows and row pointers ----------------------------------------------------------------------
-    stage_rows(r0, T);
-    stage_rowptr(r0, 0);
-    if (r0 + 16 < r1) { stage_rows(r0 + 16, Hs); stage_rowptr(r0 + 16, 1); }
-    bool open = open_segment();
-    while (open) {
-        // a segment starts cold: its first three index chunks, then everything that is under way has to land
-        const int64_t k0 = (base + seg_beg) >> 6;
-        load_chunk(k0); load_chunk(k0 + 1); load_chunk(k0 + 2);
-        int64_t k_loaded = k0 + 2;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!entered) { enter_row(false); entered = true; }                         // (the very first row: its pointers have just landed)
-        uint32_t e_i = seg_beg, e_c = seg_beg;
-        int inflight = 0, slot_i = 0, slot_c = 0;
-        for (;;) {
-            while (inflight < GD_NBUF && e_i < seg_end) {
-                asm volatile("" ::: "memory");
-                issue_batch(e_i, slot_i);
-                e_i += GD_B;
-                const int64_t k_i = (base + e_i) >> 6;                              // the issue cursor's chunk: keep two more ahead of it
-                while (k_loaded < k_i + 2) load_chunk(++k_loaded);
-                ++inflight;
-                slot_i = slot_i + 1 == GD_NBUF ? 0 : slot_i + 1;
-            }
-            if (inflight == 0) break;
-            // the oldest batch: all but the youngest (inflight - 1) batches' gathers (index chunks and stores in between only make it stricter)
-            if (inflight == 4)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (GD_B / 2)) : "memory");
-            else if (inflight == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (GD_B / 2)) : "memory");
-            else if (inflight == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * (GD_B / 2)) : "memory");
-            else                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ++since_switch;
-            const uint32_t left = seg_end - e_c;
-            add_batch(e_c, left < GD_B ? (int)left : GD_B, slot_c);
-            e_c += GD_B;
-            --inflight;
-            slot_c = slot_c + 1 == GD_NBUF ? 0 : slot_c + 1;
-        }
-        seg_beg = seg_end;
-        open = open_segment();
-    }
-    if (!entered) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); enter_row(false); }                 // (a range without a single entry)
-    while (r < r1) finish_row();                                                   // the rows after the last entry; the last tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-#endif  // GNX_TUNING
 
 // ---- long rows ---------------------------------------------------------------------------------
 template <int VEC, int U>
@@ -1372,9 +1086,6 @@ int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s) {
 #else
     p.tune = 0;
 #endif
-#ifdef GNX_TUNING   // A/B switch of the tuning build: bit 1 << 22 = entry ranges through rowptr[row_order[slot]] as before round 4
-    if (p.tune & (1 << 22)) p.slot_beg = nullptr;
-#endif
     p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
     p.partial = nullptr;
     if (p.tune & 16384) p.ldx = 0;             // (tuning builds: every gather reads row 0 -- what a launch costs without its gather misses; wrong results)
@@ -1596,14 +1307,6 @@ int gnx_spmm_tv(gnx_graph_t g, const float *d_vals_t, const float *d_diag, const
     return launch_spmm(g, g->t, p, s);
 }
 
-#ifdef GNX_TUNING
-// (the experimental one-launch form at C = 128: GNX_GCNII_DMA=1)
-static bool gcnii_dma_enabled() {
-    static const bool on = [] { const char *e = getenv("GNX_GCNII_DMA"); return e && e[0] == '1'; }();
-    return on;
-}
-#endif
-
 int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const float *d_H0, float a, int64_t C, const float *d_M,
                    int64_t ldm, int act, float *d_out, float *d_mixed, void *stream) {
     int rc = check_common("gnx_gcnii_step", g, d_H, C, C, d_H0, C, d_out, C);
@@ -1618,52 +1321,6 @@ int gnx_gcnii_step(gnx_graph_t g, const float *d_vals, const float *d_H, const f
     // C = 128 fits the kernel (135 KB of LDS: one block of eight waves per CU) and was measured: 19.2 ms against 11.8 ms for the two
     // launches on the config-4 graph -- eight waves per CU cannot keep the gathers fed -- so it takes the two-launch form
     const bool fusable = (C == 16 || C == 32 || C == 64) && aligned(d_H, 16) && aligned(d_H0, 16) && aligned(d_out, 16) && aligned(d_mixed, 16);
-#ifdef GNX_TUNING
-    if (C == 128 && gcnii_dma_enabled() && aligned(d_H, 16) && aligned(d_H0, 16) && aligned(d_out, 16) && aligned(d_mixed, 16) && m.n_rows >= (1 << 16) &&
-        m.n_rows < (1ll << 31) && m.nnz > 0) {
-        SpmmArgs p{};
-        p.vals = d_vals ? d_vals : g->raw_vals;
-        p.X = d_H; p.ldx = C; p.H0 = d_H0; p.ldh0 = C; p.beta = beta; p.alpha = a; p.act = act; p.out = d_out; p.ldo = C; p.C = (int)C;
-        p.rowptr = m.rowptr; p.colidx = m.colidx; p.n_rows = m.n_rows; p.n_nonempty = m.n_nonempty; p.row_order = m.row_order;
-        p.long_rows = m.long_rows; p.long_chunk_ptr = m.long_chunk_ptr; p.chunk_long = m.chunk_long; p.chunk_order = m.chunk_order;
-        p.n_long = m.n_long; p.n_chunks = m.n_chunks; p.long_row = m.long_row; p.long_chunk = m.long_chunk;
-        static PerDeviceOnce configured;
-        const int attr_dev = PerDeviceOnce::device();
-        if (configured.need(attr_dev)) {
-            GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-            GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-            GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-            GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gcnii_dma<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
-            configured.set(attr_dev);
-        }
-        int cus = 256, dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int64_t n_tiles = (m.n_rows + 15) / 16;
-        const int64_t tiles_per_wave = (n_tiles + (int64_t)cus * 4 - 1) / ((int64_t)cus * 4);
-        const int64_t waves = (n_tiles + tiles_per_wave - 1) / tiles_per_wave;
-        const size_t lds_bytes = (size_t)4 * GD_LDS_WORDS * sizeof(float);
-        const dim3 grid((unsigned)((waves + 3) / 4));
-        const bool relu = act == GNX_ACT_RELU, keep = d_mixed != nullptr;
-        if (relu && keep)       hipLaunchKernelGGL((k_gcnii_dma<true, true>), grid, dim3(256), lds_bytes, s, p, d_M, ldm, d_mixed, (uint32_t)tiles_per_wave, (int64_t)m.nnz);
-        else if (relu)          hipLaunchKernelGGL((k_gcnii_dma<true, false>), grid, dim3(256), lds_bytes, s, p, d_M, ldm, d_mixed, (uint32_t)tiles_per_wave, (int64_t)m.nnz);
-        else if (keep)          hipLaunchKernelGGL((k_gcnii_dma<false, true>), grid, dim3(256), lds_bytes, s, p, d_M, ldm, d_mixed, (uint32_t)tiles_per_wave, (int64_t)m.nnz);
-        else                    hipLaunchKernelGGL((k_gcnii_dma<false, false>), grid, dim3(256), lds_bytes, s, p, d_M, ldm, d_mixed, (uint32_t)tiles_per_wave, (int64_t)m.nnz);
-        g->last_kernel = "gcnii_dma_mfma";
-        if (m.n_long > 0) {   // hub rows, as below
-            rc = ensure_partial(g, (size_t)m.n_chunks * (size_t)C * sizeof(float), s);
-            if (rc != GNX_OK) return rc;
-            p.partial = g->partial;
-            p.act = GNX_ACT_NONE;
-            float *rows_at = d_mixed ? d_mixed : d_out;
-            p.out = rows_at;
-            launch_long<4>(p, s);
-            rc = dense_rows(rows_at, C, m.n_long, C, d_M, ldm, C, nullptr, act, m.long_rows, m.long_rows, d_out, C, s);
-            if (rc != GNX_OK) return rc;
-        }
-        GNX_HIP(hipGetLastError());
-        return GNX_OK;
-    }
-#endif
     if (!fusable) {   // other widths: the fused SpMM+mix into d_mixed, then the transform on the matrix cores
         GNX_CHECK_ARG(d_mixed != nullptr, "gnx_gcnii_step: width %lld needs d_mixed [n, C] (the mixed rows go through memory)", (long long)C);
         rc = gnx_spmm(g, d_vals, nullptr, d_H, C, C, d_H0, C, beta, a, GNX_ACT_NONE, d_mixed, C, stream);
@@ -1706,7 +1363,13 @@ int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const 
 
 int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0, float a, int K,
                         int64_t C, float *d_out, float *d_work, void *stream) {
+    return gnx_appnp_propagate_act(g, d_vals, d_diag, d_H0, a, K, C, GNX_ACT_NONE, d_out, d_work, stream);
+}
+
+int gnx_appnp_propagate_act(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0, float a, int K,
+                            int64_t C, int act, float *d_out, float *d_work, void *stream) {
     GNX_CHECK_ARG(g != nullptr, "gnx_appnp_propagate: NULL handle");
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_RELU, "gnx_appnp_propagate: invalid activation %d", act);
     GNX_CHECK_ARG(K >= 0, "gnx_appnp_propagate: negative iteration count");
     GNX_CHECK_ARG(g->a.n_rows == g->a.n_cols, "gnx_appnp_propagate: needs a square graph");
     GNX_CHECK_ARG(d_H0 && d_out && (K < 2 || d_work), "gnx_appnp_propagate: NULL buffer");
@@ -1717,11 +1380,6 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
     }
     const int64_t n = g->a.n_rows;
     hipStream_t s = (hipStream_t)stream;
-#ifdef GNX_TUNING   // (A/B switch of the tuning build: bit 1 << 20 = treat rows without entries as possibly referenced, the rule before round 4)
-    struct Restore { gnx_graph *g; bool a, r; ~Restore() { g->a.empty_rows_unreferenced = a; g->r.empty_rows_unreferenced = r; } }
-        restore{g, g->a.empty_rows_unreferenced, g->r.empty_rows_unreferenced};
-    if (tune_override >= 0 && (tune_override & (1 << 20))) g->a.empty_rows_unreferenced = g->r.empty_rows_unreferenced = false;
-#endif
     // Narrow features on a large graph: every gather moves a whole 128-byte line for a 16..64-byte row, so what counts is how
     // often a line is found in cache.  The K iterations then run on the degree-relabelled copy of the matrix (hub rows adjacent:
     // four to eight of the rows that receive most gathers share a line): H0 is permuted once on the way in, the LAST iteration
@@ -1745,7 +1403,8 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
             SpmmArgs p{};
             p.vals = g->r_vals; p.X = src; p.ldx = C; p.H0 = g->r_feat; p.ldh0 = C; p.beta = (float)(1.0 - (double)a); p.alpha = a;
             // rows without entries: written by the last iteration (it scatters every row); in between only if somebody gathers them
-            p.act = (!last && (k >= 2 || g->r.empty_rows_unreferenced)) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
+            // (with a relu such a row is relu(a * H0) after every iteration: just as constant)
+            p.act = (!last && (k >= 2 || g->r.empty_rows_unreferenced)) ? (act | GNX_ACT_SKIP_EMPTY) : act;
             p.out = dst; p.ldo = C; p.C = (int)C;
             p.out_rows = last ? g->r_order : nullptr;               // relabelled row i is the caller's row r_order[i]
             rc = launch_spmm(g, g->r, p, s);
@@ -1754,7 +1413,7 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
         }
         return GNX_OK;
     }
-    // A row without entries is a * H0 after every iteration and nobody's sum depends on when it was written: such rows are
+    // A row without entries is act(a * H0) after every iteration and nobody's sum depends on when it was written: such rows are
     // computed the first time each of the two buffers is a destination (k = 0, 1) and left alone afterwards (GNX_ACT_SKIP_EMPTY)
     // -- on the R-MAT workloads 60 % of the rows, 7-10 % of an iteration's bytes.  Same arithmetic, same bits.
     const float *src = d_H0;
@@ -1763,9 +1422,8 @@ int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag,
         // ... and when no entry points at such a row (g->a.empty_rows_unreferenced: every symmetric pattern) nobody ever gathers it: the
         // work buffer never needs it, the result buffer gets it the first time it is a destination
         const bool settled = k >= 2 || (g->a.empty_rows_unreferenced && dst == d_work);
-        const int act = (settled && d_diag == nullptr) ? (GNX_ACT_NONE | GNX_ACT_SKIP_EMPTY) : GNX_ACT_NONE;
-        GNX_CHECK_ARG(d_H0 != nullptr, "gnx_appnp_propagate: NULL H0");
-        int rc = gnx_spmm(g, d_vals, d_diag, src, C, C, d_H0, C, (float)(1.0 - (double)a), a, act, dst, C, stream);
+        const int act_k = (settled && d_diag == nullptr) ? (act | GNX_ACT_SKIP_EMPTY) : act;
+        int rc = gnx_spmm(g, d_vals, d_diag, src, C, C, d_H0, C, (float)(1.0 - (double)a), a, act_k, dst, C, stream);
         if (rc != GNX_OK) return rc;
         src = dst;
     }

@@ -60,6 +60,8 @@ SIGNATURES = {
     "gnx_ppr_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p, c_void_p]),
     "gnx_appnp_propagate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_void_p, c_void_p,
                                     c_void_p]),
+    "gnx_appnp_propagate_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int64, c_int, c_void_p, c_void_p,
+                                        c_void_p]),
     "gnx_halo_plan_create": (c_int, [c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p)]),
     "gnx_halo_plan_destroy": (c_int, [c_void_p]),
     "gnx_halo_plan_layout": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p,

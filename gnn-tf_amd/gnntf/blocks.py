@@ -20,6 +20,11 @@ def linear(x):
 relu = torch.relu
 
 
+def is_relu(fn) -> bool:
+    """Whether an activation argument is the relu (under any of its torch names): what the kernels can run in their epilogue."""
+    return fn is torch.relu or fn is torch.nn.functional.relu
+
+
 def affine(features, W, b, activation=linear):
     """activation(features . W + b) -- layers.py:136.  Device tensors: gnx_dense (MFMA) with the bias and a relu fused;
     SparseRows: the SpMM kernel over the rows of W; CPU tensors: torch."""

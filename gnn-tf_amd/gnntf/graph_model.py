@@ -14,7 +14,7 @@ import math
 import torch
 
 from . import ordering, sparse
-from .blocks import Concatenate, Dense, Dropout, affine, linear, relu
+from .blocks import Concatenate, Dense, Dropout, affine, is_relu, linear, relu
 from .params import default_device
 from .protocol import Layer
 from .training import Trainable
@@ -117,8 +117,9 @@ class GNN(Trainable):
         return self._adjacency_cache[key]
 
 
-def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout):
+def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout, with_relu=False):
     """``iterations`` PPR steps from H0 through the fused loop (what PPRLoop and a run of plain PPRIteration layers execute).
+    ``with_relu``: relu after every step (the reference's ``activation`` argument, filter.py:22,28,35), in the kernels' epilogue.
     Returns (result, run) with run(k) = the value after the first k iterations (for the intermediate layers' lazy ``.value``)."""
     training = graph_dropout != 0 and architecture.is_training()
     cheap = True                                                # asking make_adj for an iteration's adjacency again costs nothing
@@ -145,9 +146,9 @@ def _propagation_run(architecture: "GNN", H0_value, a, iterations, graph_dropout
         adj = architecture.get_adjacency(graph_dropout)
         make_adj = lambda k, bwd=False: adj
     if not torch.is_grad_enabled() and not training:
-        run = lambda k: sparse.appnp_propagate(make_adj(0, False), H0_value, a, k)
+        run = lambda k: sparse.appnp_propagate(make_adj(0, False), H0_value, a, k, relu=with_relu)
     else:
-        run = lambda k: sparse.ppr_loop(make_adj, H0_value, a, k)
+        run = lambda k: sparse.ppr_loop(make_adj, H0_value, a, k, relu=with_relu)
     return run(iterations), run, (make_adj if cheap else None)
 
 
@@ -156,7 +157,8 @@ class PPRIteration(Layer):
 
     A RUN of such layers as user code builds it (reference demos/custom_layers.py:8-13: ``for _ in range(10):
     gnn.add(PPRIteration(H0, 0.1))``) executes as one fused loop when the layers are plain -- the same H0 layer, one float restart
-    probability, identity activation and restart transform, no feature dropout, one graph_dropout -- and the run starts from
+    probability, the identity or relu as the activation of ALL of them (relu runs in the kernels' epilogue, gnx_appnp_propagate_act),
+    identity restart transform, no feature dropout, one graph_dropout -- and the run starts from
     H0's own value: the same arithmetic and the same sequence of edge-dropout masks as layer by layer (bitwise on graphs below
     2^20 vertices; above, narrow widths run on the relabelled copy: float32 rounding), at the cost of the PPRLoop layer.  The last
     layer of the run holds the result; the ``.value`` of an intermediate layer is computed when somebody reads it.
@@ -192,7 +194,8 @@ class PPRIteration(Layer):
 
     def _plain(self):
         a = self.restart_probability
-        return (type(self) is PPRIteration and isinstance(a, (int, float)) and not isinstance(a, bool) and self.activation is linear
+        return (type(self) is PPRIteration and isinstance(a, (int, float)) and not isinstance(a, bool)
+                and (self.activation is linear or is_relu(self.activation))
                 and self.restart_transform is linear and self.dropout == 0 and self.output_regularize == 0)
 
     def __run__(self, architecture: GNN, features, stack, at):
@@ -203,12 +206,13 @@ class PPRIteration(Layer):
         for layer in stack[at + 1:]:
             if not (isinstance(layer, PPRIteration) and layer._plain() and layer.H0 is self.H0 and layer is not self
                     and layer.restart_probability == self.restart_probability and layer.graph_dropout == self.graph_dropout
-                    and all(layer is not seen for seen in run)):
+                    and (layer.activation is self.activation or (is_relu(layer.activation) and is_relu(self.activation))) and all(layer is not seen for seen in run)):
                 break
             run.append(layer)
         if len(run) < 2:
             return None
-        out, upto, make_adj = _propagation_run(architecture, features, float(self.restart_probability), len(run), self.graph_dropout)
+        out, upto, make_adj = _propagation_run(architecture, features, float(self.restart_probability), len(run), self.graph_dropout,
+                                               with_relu=is_relu(self.activation))
         for k, layer in enumerate(run[:-1]):
             layer.__dict__["_value"], layer.__dict__["_pending_value"] = None, (lambda k=k: upto(k + 1))
         run[-1].value = out

@@ -448,17 +448,22 @@ class _PPRLoop(torch.autograd.Function):
     stored activations: g_k = (1-a) A_k^T g_{k+1}, dH0 = g_0 + a * sum_k g_{k+1}.  In training mode
     every iteration has its own dropped + re-normalised adjacency A_k (filter.py:18 calls get_adjacency
     each time); the counter RNG lets the backward REGENERATE A_k from (seed, stream id) instead of
-    keeping K value arrays alive."""
+    keeping K value arrays alive.
+    ``relu`` (the reference's per-iteration activation, filter.py:22): H_k = relu(Z_k) in every launch's epilogue; the backward then
+    needs the sign of every Z_k, so the K outputs ARE kept (what the layer-by-layer form keeps anyway) and every gradient is
+    masked by H_k > 0 before it goes through A_k^T: gz_k = g_k * (H_k > 0), g_{k-1} = (1-a) A_k^T gz_k, dH0 = g_0 + a sum_k gz_k."""
 
     @staticmethod
-    def forward(ctx, H0, make_adj, a, K):
-        ctx.make_adj, ctx.a, ctx.K = make_adj, a, K
+    def forward(ctx, H0, make_adj, a, K, relu=False):
+        ctx.make_adj, ctx.a, ctx.K, ctx.relu = make_adj, a, K, relu
+        act = nat.ACT_RELU if relu else nat.ACT_NONE
         H0 = _as_f32_rows(H0).contiguous()
         ctx.C = C = H0.shape[1]
         H0 = _padded(H0, friendly_width(C, H0.shape[0]))
         H = H0
         first = make_adj(0, False) if K > 0 else None
-        if K > 1 and isinstance(first, DroppedAdjacency):
+        kept = []
+        if K > 1 and isinstance(first, DroppedAdjacency) and not relu:
             # weights made in the kernels (only the K degree-scale vectors exist): the next iteration's column scale rides out with
             # the rows, so from k = 1 on no per-entry scale gather is left (gnx_spmm_dropped_chained)
             adjs = [first] + [make_adj(k, False) for k in range(1, K)]
@@ -473,7 +478,11 @@ class _PPRLoop(torch.autograd.Function):
                     H = _launch(adj, H, H0, 1.0 - a, a, nat.ACT_NONE)
         else:
             for k in range(K):           # one adjacency alive at a time (a materialised one is an nnz-sized array)
-                H = _launch(first if k == 0 else make_adj(k, False), H, H0, 1.0 - a, a, nat.ACT_NONE)
+                H = _launch(first if k == 0 else make_adj(k, False), H, H0, 1.0 - a, a, act)
+                if relu:
+                    kept.append(H)
+        if relu:
+            ctx.save_for_backward(*kept)
         return H if H.shape[1] == C else H[:, :C].contiguous()
 
     @staticmethod
@@ -485,18 +494,21 @@ class _PPRLoop(torch.autograd.Function):
             adjs = [ctx.make_adj(k, True) for k in range(ctx.K)]
             if all(isinstance(adj, DroppedAdjacency) for adj in adjs):
                 gH0 = _backward_chained(adjs, g, ctx.a)
-                return (gH0 if gH0.shape[1] == ctx.C else gH0[:, :ctx.C].contiguous()), None, None, None
+                return (gH0 if gH0.shape[1] == ctx.C else gH0[:, :ctx.C].contiguous()), None, None, None, None
+        outs = ctx.saved_tensors if ctx.relu else None
         room = int(0.1 * torch.cuda.get_device_properties(g.device).total_memory) // max(g.numel() * 4, 1)
         limit = max(2, min(LINCOMB_TERMS - 1, room))
         pending, total = [], None
         for k in range(ctx.K - 1, -1, -1):
+            if outs is not None:
+                g = _relu_mask(g, outs[k])
             pending.append((g, ctx.a))
             if len(pending) >= limit:
                 total, pending = linear_combination(([(total, 1.0)] if total is not None else []) + pending), []
             g = _launch(ctx.make_adj(k, True), g, None, 1.0 - ctx.a, 0.0, nat.ACT_NONE, transposed=True)
         pending.append((g, 1.0))
         gH0 = linear_combination(([(total, 1.0)] if total is not None else []) + pending)
-        return (gH0 if gH0.shape[1] == ctx.C else gH0[:, :ctx.C].contiguous()), None, None, None
+        return (gH0 if gH0.shape[1] == ctx.C else gH0[:, :ctx.C].contiguous()), None, None, None, None
 
 
 LINCOMB_TERMS = 16
@@ -524,11 +536,11 @@ def linear_combination(terms) -> torch.Tensor:
     return out
 
 
-def ppr_loop(make_adj, H0: torch.Tensor, a: float, iterations: int) -> torch.Tensor:
+def ppr_loop(make_adj, H0: torch.Tensor, a: float, iterations: int, relu: bool = False) -> torch.Tensor:
     """``iterations`` fused PPR steps starting from H0; ``make_adj(k, for_backward)`` returns the Adjacency
     of iteration k (called again, with the same k and for_backward=True, during the backward, where only the
-    transposed-order values are needed)."""
-    return _PPRLoop.apply(H0, make_adj, float(a), int(iterations))
+    transposed-order values are needed).  ``relu``: relu after every step (filter.py:22)."""
+    return _PPRLoop.apply(H0, make_adj, float(a), int(iterations), bool(relu))
 
 
 class _SpMMBiasAct(torch.autograd.Function):
@@ -570,9 +582,10 @@ def ppr_step(adj: Adjacency, H: torch.Tensor, H0: torch.Tensor, a) -> torch.Tens
     return _PPRStep.apply(H, H0, adj, float(a))
 
 
-def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations: int = 10) -> torch.Tensor:
+def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations: int = 10, relu: bool = False) -> torch.Tensor:
     """The eval-mode K-iteration loop as ONE library call with two ping-pong buffers
-    (no autograd, no per-layer .value caching) -- the measured hot path."""
+    (no autograd, no per-layer .value caching) -- the measured hot path.  ``relu``: the reference's per-iteration activation
+    (filter.py:22,28,35) in every iteration's epilogue (gnx_appnp_propagate_act)."""
     g = adj.graph
     nat.require_cuda(H0)
     H0 = _as_f32_rows(H0).contiguous()
@@ -583,9 +596,9 @@ def appnp_propagate(adj: Adjacency, H0: torch.Tensor, a: float = 0.1, iterations
     out = torch.empty_like(H0)
     work = torch.empty_like(H0) if iterations > 1 else None
     with nat.on_device(H0.device):
-        nat.check(nat.lib().gnx_appnp_propagate(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(H0), float(a),
-                                                int(iterations), H0.shape[1], nat.ptr(out), nat.ptr(work),
-                                                nat.current_stream()))
+        nat.check(nat.lib().gnx_appnp_propagate_act(g.handle, nat.ptr(adj.vals), nat.ptr(adj.diag), nat.ptr(H0), float(a),
+                                                    int(iterations), H0.shape[1], nat.ACT_RELU if relu else nat.ACT_NONE,
+                                                    nat.ptr(out), nat.ptr(work), nat.current_stream()))
     return out if out.shape[1] == C else out[:, :C].contiguous()
 
 

@@ -274,6 +274,13 @@ int gnx_ppr_step(gnx_graph_t g, const float *d_vals, const float *d_diag, const 
 int gnx_appnp_propagate(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0,
                         float a, int K, int64_t C, float *d_out, float *d_work, void *stream);
 
+/* The same loop with the reference's per-iteration activation (filter.py:22,28,35: APPNP hands its ``activation`` to every
+ * PPRIteration): H <- act((A_hat . H)*(1-a) + H0*a), act = GNX_ACT_NONE (= gnx_appnp_propagate) or GNX_ACT_RELU, applied in every
+ * iteration's epilogue -- bit for bit what K gnx_ppr_step calls with that act return (below the relabelling threshold).  A row
+ * without entries is act(a * H0) after every iteration, so the settled-row rule above holds unchanged. */
+int gnx_appnp_propagate_act(gnx_graph_t g, const float *d_vals, const float *d_diag, const float *d_H0,
+                            float a, int K, int64_t C, int act, float *d_out, float *d_work, void *stream);
+
 /* One GCNIILayer.__forward__ (gnntf/core/gnn/architectures/gcn.py:22-27) with a fixed adjacency:
  *   out = act( ((A_hat . H)*(1-a) + H0*a) . M ),   M = (1-b) I + b W  given by the caller as a [C, C] matrix (ldm).
  * For C in {16, 32, 64} (16-byte aligned buffers) this is ONE launch for all rows of at most 512 entries: the mixed rows

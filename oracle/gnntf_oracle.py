@@ -218,16 +218,17 @@ def ppr_iteration(adj_indices, adj_values, shape, H, H0, a=0.1, activation=None)
 
 def appnp_propagate(indices, values, shape, H0, a=0.1, iterations=10, graph_dropout=0.5,
                     normalized="symmetric", add_eye="none", training=False, seed=0,
-                    first_stream=0, dtype=np.float32):
+                    first_stream=0, dtype=np.float32, activation=None):
     """The K-iteration hot loop (filter.py:34-35 adds K PPRIteration layers; each one
     calls get_adjacency again, filter.py:18) starting from H = H0 (the Dense layer's
-    value feeds the first iteration, layered.py:52-55)."""
+    value feeds the first iteration, layered.py:52-55).  ``activation``: APPNP's
+    argument of that name, handed to every PPRIteration (filter.py:28,35 -> :22)."""
     H0 = np.asarray(H0).astype(dtype)
     H = H0
     for k in range(iterations):
         ai, av = get_adjacency(indices, values, shape, graph_dropout, normalized, add_eye,
                                training, seed, first_stream + k, dtype)
-        H = ppr_iteration(ai, av, shape, H, H0, a)
+        H = ppr_iteration(ai, av, shape, H, H0, a, activation)
     return H
 
 

@@ -1245,3 +1245,137 @@ def test_stream_yardsticks_move_every_element(gnntf, n):
     ones = torch.ones(n, dtype=torch.float32, device="cuda")
     nat.check(nat.lib().gnx_stream_read(nat.ptr(ones), n, nat.ptr(sink), nat.current_stream()))
     assert float(sink.double().sum()) == n                      # per-wave sums of ones are exact; the 64 slots hold them all
+
+
+# ---- the K loop with the reference's per-iteration activation (filter.py:22,28,35), fused ---------------------------------
+@pytest.mark.parametrize("C", [1, 7, 16, 40, 64, 256])
+def test_k_loop_with_relu_in_the_epilogue(gnntf, C):
+    """gnx_appnp_propagate_act(GNX_ACT_RELU): relu after EVERY iteration inside the one library call.  Against the oracle's
+    K-iteration loop with activation = relu; bit for bit what K single steps with the relu flag return; rows without entries
+    (relu(a * H0) after every iteration) and long rows included; K = 0, 1, 2 (the ping-pong's corner cases)."""
+    from gnntf import _native as nat
+    from gnntf.sparse import _launch
+    n = 3000
+    coo, vals, shape = graphs.random_coo(n, n, 40000, seed=C, weighted=True, dup_frac=0.1)
+    coo[:9000, 0] = 17                                                     # a long row (hub)
+    keep = ~np.isin(coo[:, 0], np.arange(100, 400))                        # 300 rows without entries
+    coo, vals = coo[keep], vals[keep]
+    g = make_graph(gnntf, coo, vals, shape)
+    adj = gnntf.normalize(g, "symmetric")
+    H0 = np.random.default_rng(C).standard_normal((n, C)).astype(np.float32)
+    for K in (0, 1, 2, 5, 10):
+        got = gnntf.appnp_propagate(adj, dev(H0), a=0.15, iterations=K, relu=True)
+        want = orc.appnp_propagate(coo, vals, shape, H0, a=0.15, iterations=K, activation=orc.relu)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+        H = dev(H0)
+        for _ in range(K):
+            H = _launch(adj, H, dev(H0), 0.85, 0.15, nat.ACT_RELU)
+        assert torch.equal(got, H), (C, K)
+        if K > 0:
+            assert float(got.min()) >= 0.0
+            empty = got[100:400].cpu().numpy()
+            np.testing.assert_array_equal(empty, np.maximum(np.float32(0.15) * H0[100:400], 0))
+    # and the plain loop is still the plain loop
+    assert torch.equal(gnntf.appnp_propagate(adj, dev(H0), a=0.15, iterations=3), gnntf.appnp_propagate(adj, dev(H0), a=0.15, iterations=3, relu=False))
+    lib = nat.lib()
+    X, out, work = dev(H0), torch.empty(n, C, device="cuda"), torch.empty(n, C, device="cuda")
+    assert lib.gnx_appnp_propagate_act(g.handle, nat.ptr(adj.vals), None, nat.ptr(X), 0.1, 3, C, 7, nat.ptr(out), nat.ptr(work), nat.current_stream()) == -1
+    assert b"invalid activation" in lib.gnx_last_error()
+
+
+def test_appnp_with_relu_activation_runs_fused(gnntf):
+    """APPNP(..., activation=relu) (filter.py:28,35: the activation goes to every PPRIteration): in eval mode the K layers run as ONE
+    library call and return bit for bit what the layer-by-layer container returns; in training mode the same masks and outputs, and
+    gradients equal to the layer-by-layer form's."""
+    coo, vals, shape = graphs.cora_shaped(seed=5)[:3]
+    X = np.random.default_rng(1).standard_normal((shape[0], 24)).astype(np.float32)
+
+    def build(act):
+        gnntf.set_seed(7)
+        return gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), X, num_classes=7, latent_dims=[16], activation=act)
+    fused, plain = build(gnntf.relu), build(torch.nn.functional.relu)
+    plain.fuse_runs = False
+    for m in (fused, plain):
+        m.reset()
+    for v, w in zip(fused.vars(), plain.vars()):
+        w.assign(v.identity())
+    assert [type(l).__name__ for l in fused.layers()] == ["Dropout", "Dense", "Dense"] + ["PPRIteration"] * 10
+    calls, steps = [], []
+    real_loop, real_step = gnntf.sparse.appnp_propagate, gnntf.sparse.ppr_step
+    fused.training_mode(False); plain.training_mode(False)
+    with torch.no_grad():
+        gnntf.sparse.appnp_propagate = lambda *a, **k: (calls.append(k.get("relu")), real_loop(*a, **k))[1]
+        gnntf.sparse.ppr_step = lambda *a, **k: (steps.append(1), real_step(*a, **k))[1]
+        try:
+            out_f = fused(fused.features)
+            assert calls == [True] and not steps                          # one library call, with the relu flag
+            out_p = plain(plain.features)
+            assert len(steps) == 10
+        finally:
+            gnntf.sparse.appnp_propagate, gnntf.sparse.ppr_step = real_loop, real_step
+        assert torch.equal(out_f, out_p) and float(out_f.min()) >= 0.0
+        its_f = [l for l in fused.layers() if isinstance(l, gnntf.PPRIteration)]
+        its_p = [l for l in plain.layers() if isinstance(l, gnntf.PPRIteration)]
+        for k in (0, 5):                                                   # an intermediate iteration's value: computed when read
+            assert torch.equal(its_f[k].value, its_p[k].value)
+    outs, grads = [], []
+    for model in (fused, plain):
+        gnntf.set_seed(11)
+        model._mask_calls = 0
+        for v in model.vars():
+            v.var.grad = None
+        with model:
+            out = model(model.features)
+            (out * out).sum().backward()
+        outs.append(out.detach())
+        grads.append([v.var.grad.clone() for v in model.vars() if v.trainable])
+    assert torch.equal(outs[0], outs[1])
+    assert any(float(gr.abs().max()) > 0 for gr in grads[0])
+    for gf, gp in zip(grads[0], grads[1]):
+        np.testing.assert_allclose(gf.cpu().numpy(), gp.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # a run whose layers disagree about the activation is not ONE run: relu x 3 then identity x 3 = two fused calls
+    gnntf.set_seed(7)
+    mixed = gnntf.GNN(gnntf.SparseCOO(coo, vals, shape), X)
+    H0 = mixed.add(gnntf.Dense(7, regularize=False))
+    for k in range(6):
+        mixed.add(gnntf.PPRIteration(H0, 0.1, activation=gnntf.relu if k < 3 else gnntf.linear))
+    mixed.reset(); mixed.training_mode(False)
+    with torch.no_grad():
+        got = mixed(mixed.features)
+        mixed.fuse_runs = False
+        assert torch.equal(got, mixed(mixed.features))
+
+
+@pytest.mark.parametrize("C,duplicates", [(7, False), (64, False), (7, True)])
+def test_relu_loop_backward_against_dense_float64(gnntf, C, duplicates):
+    """The training node with relu: K iterations, each with its own dropped + renormalised adjacency (layered.py:47-50, gnn.py:37-42),
+    relu after each (filter.py:22).  Forward and dH0 against the same recurrence in dense float64 with the ORACLE's per-iteration
+    adjacencies (autograd on the CPU)."""
+    n, K, a, p, seed, first = 300, 4, 0.1, 0.5, 5, 3
+    coo, vals, shape = graphs.random_coo(n, n, 4000, seed=77, weighted=True)
+    if not duplicates:                                                     # every entry once: the weights are then made inside the SpMM
+        _, first_at = np.unique(coo[:, 0] * n + coo[:, 1], return_index=True)
+        coo, vals = coo[np.sort(first_at)], vals[np.sort(first_at)]
+    g = make_graph(gnntf, coo, vals, shape)
+    assert gnntf.sparse.can_fuse_dropout(g, p) == (not duplicates)
+    rng = np.random.default_rng(C)
+    H0np, gout = rng.standard_normal((n, C)).astype(np.float32), rng.standard_normal((n, C)).astype(np.float32)
+    if gnntf.sparse.can_fuse_dropout(g, p):
+        scales = gnntf.sparse.dropped_degree_scales(g, p, seed, first, K)
+        make = lambda k, bwd=False: gnntf.sparse.dropped_adjacency(g, p, seed, first + k, D=scales[k])
+    else:
+        make = lambda k, bwd=False: gnntf.normalize(g, "symmetric", "none", p, seed, first + k, transposed_only=bwd)
+    H0 = dev(H0np).requires_grad_()
+    out = gnntf.ppr_loop(make, H0, a, K, relu=True)
+    out.backward(dev(gout))
+    H0d = torch.tensor(H0np, dtype=torch.float64, requires_grad=True)
+    H = H0d
+    for k in range(K):
+        ai, av = orc.get_adjacency(coo, vals, shape, graph_dropout=p, training=True, seed=seed, stream=first + k, dtype=np.float64)
+        A = torch.tensor(orc.to_dense(ai, av, shape))
+        H = torch.relu((1 - a) * (A @ H) + a * H0d)
+    H.backward(torch.tensor(gout, dtype=torch.float64))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), H.detach().numpy(), rtol=RTOL, atol=ATOL)
+    # a gradient element differs only where a pre-activation sits within rounding of zero: none such on this seed
+    np.testing.assert_allclose(H0.grad.cpu().numpy(), H0d.grad.numpy(), rtol=1e-3, atol=1e-4)
+    assert float(H0.grad.abs().max()) > 0

@@ -12,9 +12,11 @@ export TMPDIR=/tmp
 out=${1:-gpurun_out}; shift
 mkdir -p "$out"
 if [ "$1" = "exact" ]; then
-  GNX_BENCH_BACKEND=gloo timeout -k 10 1120 python3 bench.py --gpus ${2:-2} > $out/exact_gloo.json 2> $out/exact_gloo.err
+  # (the driver's command is `bench.py --gpus N --steps 20 --warmup 5`; a host-staged step takes tens of seconds, so fewer steps here)
+  GNX_BENCH_BACKEND=gloo timeout -k 10 1120 python3 bench.py --gpus ${2:-2} --steps ${GNX_REHEARSE_STEPS:-3} --warmup 1 > $out/exact_gloo.json 2> $out/exact_gloo.err
   rc=$?
-  echo "rc=$rc"; grep "^\[bench" $out/exact_gloo.err | tail -40; tail -c 1500 $out/exact_gloo.json
+  echo "rc=$rc, line $(wc -c < $out/exact_gloo.json) bytes"; grep "^\[bench" $out/exact_gloo.err | tail -40; tail -c 1500 $out/exact_gloo.json
+  cp bench_detail_n${2:-2}.json $out/ 2>/dev/null
   exit $rc
 fi
 ranks=${@:-2 4 5}
