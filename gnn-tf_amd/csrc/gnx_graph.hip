@@ -650,7 +650,8 @@ int gnx_graph_set_row_window(gnx_graph_t g, int64_t window_rows, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     GNX_CHECK_ARG(!stream_is_capturing(s), "gnx_graph_set_row_window: the stream is being captured -- set the window before the capture begins");
     if (g->a.order_window == window_rows) return GNX_OK;
-    GNX_HIP(hipStreamSynchronize(s));                                // launches in flight on this handle's stream still read the old order
+    // launches in flight on this handle -- on ANY stream -- still read the old order's arrays, which are freed below
+    GNX_HIP(hipDeviceSynchronize());
     const int64_t before = g->a.order_window;
     free_plan(g->a);
     g->a.order_window = window_rows;
@@ -665,7 +666,10 @@ int gnx_graph_set_row_window(gnx_graph_t g, int64_t window_rows, void *stream) {
         free_plan(g->t);
         g->t.order_window = g->a.n_rows == g->a.n_cols ? window_rows : 0;
         rc = build_long_plan(g->t, s);
-        if (rc != GNX_OK) return rc;
+        if (rc != GNX_OK) {       // a half-built transposed plan must never be launched: the structure goes, the next user rebuilds it
+            drop_transpose(g);
+            return rc;
+        }
     }
     if (g->has_r) drop_relabel(g);                                   // the degree-relabelled copy belongs to the default order
     GNX_HIP(hipGetLastError());

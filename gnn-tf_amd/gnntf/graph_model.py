@@ -84,6 +84,8 @@ class GNN(Trainable):
                         order, reorder = None, None
             self.reorder_used = reorder
             if order is not None:
+                if isinstance(self.features, sparse.SparseRows):
+                    raise Exception("GNN: reorder needs dense input features")
                 self._order, self._newid = order, newid
                 coo = sparse.SparseCOO(newid[coo.indices], coo.values, coo.dense_shape)
                 self.features = self.features.index_select(0, order)

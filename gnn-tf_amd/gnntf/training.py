@@ -31,6 +31,11 @@ class Predictor(object):
 
 
 def _as_features(features):
+    from .sparse import DeviceGraph, SparseCOO, SparseRows
+    if isinstance(features, SparseCOO):                 # a sparse attribute matrix (datasets.load_gnn_benchmark_npz): never densified
+        return SparseRows(DeviceGraph(features, device=default_device()))
+    if isinstance(features, SparseRows):
+        return features
     if isinstance(features, torch.Tensor):
         return features.to(default_device(), torch.float32)
     return torch.as_tensor(np.asarray(features), dtype=torch.float32).to(default_device())
@@ -111,6 +116,11 @@ class Trainable(Layered):
         from .blocks import Dense, Dropout
         from .sparse import SparseRows
         X = self.features
+        if isinstance(X, SparseRows):                   # given sparse: only [Dropout]* Dense can take it
+            head = [layer for layer in self.layers() if not isinstance(layer, Dropout)]
+            if not head or type(head[0]) is not Dense:
+                raise Exception("sparse input features need a model whose first layers are [Dropout]* Dense")
+            return X
         if self._sparse_rows is None:
             head = [layer for layer in self.layers() if not isinstance(layer, Dropout)]
             eligible = (X.is_cuda and X.dim() == 2 and X.numel() > 0 and head and type(head[0]) is Dense

@@ -119,7 +119,9 @@ int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream);
  * line is still in a cache), and gnx_appnp_propagate does NOT run narrow widths on its degree-relabelled copy, which would scatter
  * that neighbourhood.  0 restores the default (global degree bins).  Results are the same sums in the same per-row order: bitwise
  * those of the default order except where the default would have used the relabelled copy.  Rebuilds the handle's launch plan:
- * synchronises the stream, not capturable.  Nothing in the reference corresponds (TensorFlow's kernel walks the COO as stored). */
+ * synchronises the DEVICE (work on any stream may still read the old plan's arrays, which are freed), not capturable, and
+ * INVALIDATES every hipGraph captured on this handle before the call (a replay would read the freed arrays): capture again.
+ * Nothing in the reference corresponds (TensorFlow's kernel walks the COO as stored). */
 int gnx_graph_set_row_window(gnx_graph_t g, int64_t window_rows, void *stream);
 
 /* gnx_graph_set_dropout_counter: from now on every dropout stream id used with this handle is `stream_id + *d_counter`

@@ -93,11 +93,15 @@ def dev(x):
     return torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
-def rel_rows(x, y):
-    """Per row: largest |x - y| relative to the row's largest |y|, but never to less than 1 % of the matrix's largest element: a
-    row whose terms cancel to ~1e-3 of their size (seed 303, case 1081: C = 1, |row| = 1.1e-3, terms ~ 1) carries the float32
-    noise of its terms."""
-    return ((x - y).abs() / y.abs().max(dim=1, keepdim=True).values.clamp_min(max(1e-3, 1e-2 * float(y.abs().max())))).max(dim=1).values
+def rel_rows(x, y, floor_share=1e-2):
+    """Per row: largest |x - y| relative to the row's largest |y|, but never to less than ``floor_share`` (1 %) of the matrix's
+    largest element: a row whose terms cancel to ~1e-3 of their size (seed 303, case 1081: C = 1, |row| = 1.1e-3, terms ~ 1) carries
+    the float32 noise of its terms.  The floor is for the BACKWARD comparison, where that cancellation was found; the forward
+    comparison passes floor_share = 0 (the criterion before round 5: relative to the row's own largest element, floor 1e-3)."""
+    return ((x - y).abs() / y.abs().max(dim=1, keepdim=True).values.clamp_min(max(1e-3, floor_share * float(y.abs().max())))).max(dim=1).values
+
+
+PASSED_ONLY_WITH_THE_FLOOR = [0]        # backward comparisons of this process that the 1 % floor let pass (run() reports the count)
 
 
 def training_loops(s):
@@ -185,9 +189,11 @@ def check_case(s):
             for k in range(K):
                 assert torch.equal(r["D"][k], gnntf.sparse.dropped_degree_scales(r["g"], p, DROP_SEED, case + k, 1)[0]), f"scales case {case} stream {k}"
             tol = 2e-5 * (1.0 + np.sqrt(longest) / 10.0)
-            e_f = float(rel_rows(r["f_got"], r["f_want"]).max())
+            e_f = float(rel_rows(r["f_got"], r["f_want"], floor_share=0.0).max())
             assert e_f < tol, f"chained forward case {case}: {e_f}"
             e_b = rel_rows(r["b_got"], r["b_want"])
+            if float(e_b.max()) < tol <= float(rel_rows(r["b_got"], r["b_want"], floor_share=0.0).max()):
+                PASSED_ONLY_WITH_THE_FLOOR[0] += 1
             if float(e_b.max()) >= tol:        # which of the two is off?  float64 through the materialised dropped adjacencies decides
                 ref_t = dev(backward_float64(s)[0].astype(np.float32))
                 e_chained, e_steps = float(rel_rows(r["b_got"], ref_t).max()), float(rel_rows(r["b_want"], ref_t).max())
@@ -280,6 +286,8 @@ def run(cases, seed, first=0, verbose=True):
         if verbose and case % 50 == 49:
             print(f"{case + 1} cases, {time.time() - t0:.0f} s", stats, flush=True)
     torch.cuda.synchronize()
+    if verbose or PASSED_ONLY_WITH_THE_FLOOR[0]:
+        print(f"backward comparisons that pass only with the 1 % floor of rel_rows: {PASSED_ONLY_WITH_THE_FLOOR[0]} of {stats['dropped']}", flush=True)
     return stats
 
 

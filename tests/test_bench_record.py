@@ -265,7 +265,7 @@ def full_record_with_stand_in_numbers(traffic_table, n_gpus=1):
         flat[f"train_C{W}_step_ms"] = 123.456789123
     for W in (256, 8):
         flat.update({f"config4_C{W}_via_layers_ms": 142.123456789, f"config4_C{W}_c_entry_ms": 142.023456789, f"config4_C{W}_layers_bitwise_equal_c_entry": True})
-    flat.update(config4_C8_relu_fused_forward_ms=16.123456, config4_C8_relu_layer_by_layer_forward_ms=31.123456, config4_C8_relu_fused_bitwise_equal=True,
+    flat.update(config4_C8_relu_fused_forward_ms=16.123456, config4_C8_relu_layer_by_layer_forward_ms=31.123456, config4_C8_relu_fused_max_abs_diff=2.3841858e-07,
                 config3_gcn_forward_ms=0.4123456789, config3_spmm128_edges_per_s=2.1e10, config3_spmm64_edges_per_s=3.1e10,
                 config2_eval_forward_ms=0.3123456789, config2_captured_train_ms_per_epoch=0.9123456789, train_kept_entries=50_001_234)
     cpu = {"value": 1.23456789e8, "unit": "edges/s", "cores": 16, "kind": "port", "spmm_only_value": 2.3456789e8, "sample": "y" * 560,

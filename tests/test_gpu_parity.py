@@ -803,6 +803,49 @@ def test_row_window_changes_the_launch_order_not_the_sums(gnntf, n, entries):
         g.set_row_window(-1)
 
 
+@pytest.mark.parametrize("n", [20011, 70001])
+def test_row_window_remaps_the_group_kernels_bitwise(gnntf, n):
+    """what reorder="locality" ships at narrow widths is k_spmm_group with the XCD-chunked block remap (xcd_block) over a
+    PADDED grid, reached through launch_rows -- a graph without long rows (launch_rows_and_chunks bypasses the remap) and with at
+    least 64 windows of non-empty rows.  Every row holds 3 ... 40 entries here, n is prime (the grid is no multiple of 8 chunks), and
+    window = 64 / 96 must return bit for bit what the default order returns at every sub-wave width (group4 ... group32), for a
+    single step, the K loop with settled rows trimmed, the transposed launch and a training launch."""
+    rng = np.random.default_rng(n)
+    deg = rng.integers(3, 41, size=n)
+    deg[rng.integers(0, n, size=n // 10)] = 0                               # rows without entries (trimmed slots, padded blocks)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, size=rows.size)
+    coo = np.stack([rows, cols], 1).astype(np.int64)
+    vals = (rng.random(rows.size) + 0.25).astype(np.float32)
+    g = gnntf.DeviceGraph(gnntf.SparseCOO(coo, vals, (n, n)), device="cuda:0")
+    adj = gnntf.normalize(g, "symmetric")
+    kernels = {}
+
+    def everything():
+        out = {}
+        for C in (7, 8, 12, 40, 64, 128):
+            H0 = dev(np.random.default_rng(C).standard_normal((n, C)).astype(np.float32))
+            out[C, "step"] = gnntf.ppr_step(adj, H0, H0, 0.1)
+            kernels[C] = g.last_kernel()
+            out[C, "loop"] = gnntf.appnp_propagate(adj, H0, 0.1, 4)
+            out[C, "relu_loop"] = gnntf.appnp_propagate(adj, H0, 0.1, 3, relu=True)
+            out[C, "t"] = gnntf.sparse._launch(adj, H0, None, 1.0, 0.0, 0, transposed=True)
+            out[C, "drop"] = gnntf.sparse._launch(gnntf.sparse.dropped_adjacency(g, 0.5, 3, 1), H0, H0, 0.9, 0.1, 0)
+        return out
+    base = everything()
+    assert kernels == {7: "spmm_group8", 8: "spmm_group4", 12: "spmm_group4", 40: "spmm_group16", 64: "spmm_group16", 128: "spmm_group32"}, kernels
+    for window in (64, 96):
+        assert g.n_rows - int((deg == 0).sum()) >= 64 * window            # the remap's own gate (GNX_ROW_PIECES)
+        g.set_row_window(window)
+        got = everything()
+        for key in base:
+            assert torch.equal(got[key], base[key]), (window, key, float((got[key] - base[key]).abs().max()))
+    H0 = np.random.default_rng(8).standard_normal((n, 8)).astype(np.float32)
+    want = orc.appnp_propagate(coo, vals, (n, n), H0, a=0.1, iterations=4)
+    np.testing.assert_allclose(gnntf.appnp_propagate(adj, dev(H0), 0.1, 4).cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    g.set_row_window(0)
+
+
 def test_gcnii_layer_api(gnntf):
     """GCNII reuses the fused SpMM+mix kernel (gcn.py:7-27,54-74)."""
     coo, vals, shape = graphs.rmat_symmetric_coo(1500, 12000, seed=4)
