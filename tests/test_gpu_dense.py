@@ -302,6 +302,34 @@ def test_sparse_input_features(gnntf):
     assert gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), dense_X, num_classes=7)._input_features().__class__ is torch.Tensor
 
 
+def test_features_given_sparse_are_never_densified(gnntf):
+    """The reference's own files hold the attribute matrix as a CSR (experiment_setup.py:273-282); datasets.load_gnn_benchmark_npz
+    hands it over as a SparseCOO and the model keeps it as device SparseRows: same logits, same training losses as the dense matrix."""
+    coo, vals, shape, X = graphs.cora_shaped(seed=2)
+    xi = np.stack(np.nonzero(X), 1).astype(np.int64)
+    sparse_X = gnntf.SparseCOO(xi, X[xi[:, 0], xi[:, 1]], X.shape)
+    labels = np.random.default_rng(0).integers(0, 7, size=shape[0])
+    tr = list(range(140))
+    outs, losses = [], []
+    for feats in (sparse_X, X):
+        gnntf.set_seed(3)
+        model = gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), feats, num_classes=7)
+        if feats is sparse_X:
+            assert isinstance(model.features, gnntf.SparseRows) and model._input_features() is model.features
+            assert model.features.graph.nnz == len(xi) and model.top_shape() == (shape[0], 7)
+        model.train(train=gnntf.NodeClassification(tr, labels[tr]), epochs=4, patience=10)
+        model.training_mode(False)
+        with torch.no_grad():
+            outs.append(model(model.features))
+        losses.append(float(model.loss(gnntf.NodeClassification(tr, labels[tr]))))
+    assert torch.equal(outs[0], outs[1]) and losses[0] == losses[1]
+    with pytest.raises(Exception, match="sparse input features need"):
+        gcn = gnntf.GCN(gnntf.SparseCOO(coo, vals, shape), sparse_X, num_classes=7)
+        gcn(gcn.features)
+    with pytest.raises(Exception, match="reorder needs dense input features"):
+        gnntf.APPNP(gnntf.SparseCOO(coo, vals, shape), sparse_X, num_classes=7, reorder="degree")
+
+
 def test_link_head_edge_scores(gnntf):
     """gnx_edge_scores (graph_predictor.py:122-126): logits of listed edges in one launch, with and without the DistMult
     weights, forward against float64 numpy and backward against torch autograd."""

@@ -260,3 +260,77 @@ def test_locality_order_groups_communities():
     assert not ordering.found_communities(0.35, 200_000, 4096, baseline_share=0.3)            # hubs close under the degree order too: not communities
     assert ordering.degree_order_share(idx, n, 2 * size) < 0.5 * ordering.share_within(idx, newid, 2 * size)
     assert ordering.share_within(idx, newid, 2 * size) > 0.5 and ordering.share_within(idx[:0], newid, 10) == 0.0
+
+
+# ---- the reference's own on-disk format (experiment_setup.py:273-282) and its splits (:183-201) -----------------------------------
+def _gnn_benchmark_file(tmp_path, n=60, classes=3, seed=0):
+    import scipy.sparse as sps
+    rng = np.random.default_rng(seed)
+    A = sps.random(n, n, density=0.08, random_state=1, format="csr", dtype=np.float64)
+    A.data[:] = rng.integers(1, 3, size=A.nnz)
+    X = sps.random(n, 40, density=0.05, random_state=2, format="csr", dtype=np.float64)
+    labels = rng.integers(0, classes, size=n)
+    labels[:5] = -1                                                            # unlabelled nodes
+    path = str(tmp_path / "toy.npz")
+    np.savez(path, **{"adj_matrix.data": A.data, "adj_matrix.indices": A.indices, "adj_matrix.indptr": A.indptr, "adj_matrix.shape": A.shape,
+                      "attr_matrix.data": X.data, "attr_matrix.indices": X.indices, "attr_matrix.indptr": X.indptr, "attr_matrix.shape": X.shape,
+                      "labels": labels})
+    return path, A, X, labels
+
+
+def test_gnn_benchmark_npz_is_read_as_the_reference_reads_it(tmp_path):
+    """load_npz on the gnn-benchmark layout: the adjacency is what graph2adj makes of the DiGraph the reference builds from
+    adj_matrix (one arc per stored entry with its weight, then the reversed arcs APPENDED), the attribute matrix stays sparse."""
+    import gnntf
+    from gnntf import datasets
+    path, A, X, labels = _gnn_benchmark_file(tmp_path)
+    adj, got_labels, feats, train, valid, test = gnntf.load_npz(path)
+    assert isinstance(adj, gnntf.SparseCOO) and isinstance(feats, gnntf.SparseCOO)
+    assert tuple(adj.dense_shape) == A.shape and tuple(feats.dense_shape) == X.shape
+    coo = A.tocoo()
+    idx = np.asarray(adj.indices)
+    assert idx.shape == (2 * A.nnz, 2)
+    np.testing.assert_array_equal(idx[:A.nnz], np.stack([coo.row, coo.col], 1))             # row by row, in stored order
+    np.testing.assert_array_equal(idx[A.nnz:], idx[:A.nnz, ::-1])                          # the reversed arcs, appended
+    np.testing.assert_array_equal(np.asarray(adj.values)[:A.nnz], A.data.astype(np.float32))
+    dense = np.zeros(X.shape, dtype=np.float32)
+    f_idx = np.asarray(feats.indices)
+    dense[f_idx[:, 0], f_idx[:, 1]] = np.asarray(feats.values)
+    np.testing.assert_array_equal(dense, X.toarray().astype(np.float32))
+    np.testing.assert_array_equal(got_labels, labels)
+    assert (train, valid, test) == datasets.custom_splits(labels, 20, 500, 0)
+    directed = datasets.load_gnn_benchmark_npz(path, directed=True)[0]
+    assert np.asarray(directed.indices).shape == (A.nnz, 2)
+    bad = dict(np.load(path))
+    bad["adj_matrix.indptr"] = bad["adj_matrix.indptr"][:-1]
+    np.savez(str(tmp_path / "bad.npz"), **bad)
+    with pytest.raises(Exception, match="not a consistent CSR"):
+        gnntf.load_npz(str(tmp_path / "bad.npz"))
+
+
+def test_custom_splits_follow_the_reference_recipe():
+    """experiment_setup.py:183-201 restated in the test: random.seed(seed); shuffle; first k per class train; the other labelled nodes
+    shuffled again -> validation, test.  Same generator stream as the reference's module-level random under the same seed."""
+    import random
+    from gnntf.datasets import custom_splits
+    rng = np.random.default_rng(3)
+    labels = rng.integers(0, 4, size=300)
+    labels[rng.integers(0, 300, size=20)] = -1
+    for seed, per_class, n_valid in ((0, 20, 50), (5, 7, None)):
+        random.seed(seed)
+        order = list(range(300))
+        random.shuffle(order)
+        count, want_train = {}, []
+        for pos in order:
+            if labels[pos] == -1:
+                continue
+            if count.get(labels[pos], 0) < per_class:
+                want_train.append(pos)
+                count[labels[pos]] = count.get(labels[pos], 0) + 1
+        rest = list(set(pos for pos in range(300) if labels[pos] != -1) - set(want_train))
+        random.shuffle(rest)
+        k = n_valid if n_valid is not None else len(count) * per_class
+        train, valid, test = custom_splits(labels, per_class, n_valid, seed)
+        assert train == want_train and valid == rest[:k] and test == rest[k:]
+        assert len(train) == 4 * per_class and not set(train) & set(valid) and not set(valid) & set(test)
+        assert all(labels[i] != -1 for i in train + valid + test) and len(train + valid + test) == int((labels != -1).sum())
