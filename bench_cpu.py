@@ -51,7 +51,8 @@ def cpu_baseline(g, adj, H0, args):
     cores = int(lib.oracle_num_threads())
     port = {"value": nnz / (t_norm + t_only * nnz / e), "unit": "edges/s", "cores": cores, "kind": "port",
             "spmm_only_value": e / t_only,
-            "sample_short": f"C/OpenMP oracle port, {cores} thr: 1 of {args.iterations} iter.; renorm all {nnz} entries {t_norm:.1f}s + SpMM first {rows} rows {t_only:.1f}s, scaled",
+            "sample_short": f"C/OpenMP oracle port, {cores} thr: 1 of {args.iterations} iter.; renorm all {nnz} entries {t_norm:.1f}s + "
+                            f"SpMM first {rows} rows {t_only:.1f}s, scaled",
             "sample": f"C / OpenMP port of the oracle (oracle/propagate_ref.c), all host threads: 1 of {args.iterations} iterations; the whole-graph "
                       f"renormalisation the reference does in every iteration (gnn.py:36-50 called from filter.py:18) timed over all {nnz} "
                       f"entries ({t_norm:.2f} s), SpMM + mix over the first {rows} of {n} rows ({e} entries, C={C}: {t_only:.2f} s) and scaled "

@@ -149,7 +149,8 @@ def measure_traffic_in_run(workloads, seconds=240.0, K=10):
         if w == "segments":
             child_args = ["--pmc-child", "segments", "--iterations", str(K)]
         else:
-            child_args = ["--workload", w, "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-secondary", "--pmc-in-run", "off", "--gather-yardstick", "off"]
+            child_args = ["--workload", w, "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--no-secondary", "--pmc-in-run", "off",
+                          "--gather-yardstick", "off"]
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             if time.time() - t_start > seconds:
                 problem = "time budget spent"

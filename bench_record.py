@@ -69,7 +69,8 @@ def pmc_traffic(name):
     rec = json.load(open(path)).get("workloads", {}).get(name)
     if not rec:
         return None, None
-    return float(rec["fabric_bytes_per_launch"]), f"profiles/pmc_traffic.json [{rec.get('source', '')}] -- builder-run rocprofv3 --pmc passes of this command, NOT measured in this run"
+    return float(rec["fabric_bytes_per_launch"]), (f"profiles/pmc_traffic.json [{rec.get('source', '')}] -- builder-run rocprofv3 --pmc passes of "
+                                                   f"this command, NOT measured in this run")
 
 
 FRAC_LEVEL = "fabric: bytes leaving the L2s incl. Infinity-Cache hits -- NOT DRAM bandwidth (see dram_frac_*, no_reuse_gather_*)"

@@ -260,8 +260,8 @@ def training_step(ctx):
         roof_f = br.roofline_record(n, nnz, C, ms_f * 1e-3, K, "train_forward_" + wl, ctx.measured_peak,
                                     b_alg=br.alg_bytes_dropped_iteration(n, nnz, kept, C), b_min=br.min_bytes_dropped_iteration(n, nnz, C),
                                     what="one forward TRAINING iteration (gnx_spmm_dropped_chained, "
-                                    "a middle one: weights from the counter RNG inside the SpMM, only kept entries gathered, rows without entries left to the last "
-                                    "iteration) incl. its long-row kernels")
+                                    "a middle one: weights from the counter RNG inside the SpMM, only kept entries gathered, rows without "
+                                    "entries left to the last iteration) incl. its long-row kernels")
         roof_b = br.roofline_record(n, nnz, C, ms_b * 1e-3, K, "train_backward_" + wl, ctx.measured_peak,
                                     b_alg=br.alg_bytes_dropped_iteration(n, nnz, kept, C, backward=True),
                                     b_min=br.min_bytes_dropped_iteration(n, nnz, C, backward=True),
@@ -323,7 +323,8 @@ def matrix_core_kernels(ctx):
         t_torch = median_ms(lambda: torch.relu(torch.addmm(b, X, W)), reps=5, warm=2)      # hipBLASLt GEMM + separate bias / relu passes
     mf["dense_10M_x_256_to_64_relu"] = {"ms": t_dense, "torch_addmm_relu_ms": t_torch, "TFLOPs": 2.0 * n * 256 * 64 / t_dense / 1e9,
                                         "GBs": (n * 256 * 4 + n * 64 * 4) / t_dense / 1e6, "mfma_peak_TFLOPs": 157.3,
-                                        "what": "gnx_dense (k_dense_wreg: W in registers, X through an LDS-DMA ring), float32 v_mfma_f32_16x16x4_f32; X read once from HBM"}
+                                        "what": "gnx_dense (k_dense_wreg: W in registers, X through an LDS-DMA ring), float32 v_mfma_f32_16x16x4_f32; "
+                                                "X read once from HBM"}
     from gnntf.sparse import _dense_wgrad
     Gd = torch.randn(n, 64, device=device)
     t_wgrad = median_ms(lambda: _dense_wgrad(X, Gd), reps=5, warm=2)

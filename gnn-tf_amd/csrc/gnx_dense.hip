@@ -495,7 +495,8 @@ int launch_wreg_as(const DenseArgs &p, hipStream_t s) {
     static PerDeviceOnce configured;
     const int attr_dev = PerDeviceOnce::device();
     if (configured.need(attr_dev)) {
-        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_wreg<NT, KS, RING, RELU, PAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
+        GNX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_wreg<NT, KS, RING, RELU, PAD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10));
         configured.set(attr_dev);
     }
     const int64_t n_tiles = (p.n + 15) / 16;
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(const float *__restrict__ X,
 // ---- the same gradient with the ACCUMULATORS stationary: every wave keeps a whole F x O partial in its registers --------------------
 // For F x O <= 16384 (256 x 64, 128 x 128, 64 x 64, ...: the layers of the path) one wave's 512 registers hold the complete result,
 // (F / 16) x (O / 16) accumulator tiles (wider layers: one panel of at most 128 outputs x 16384 / 128 features per wave, every slab of
-// rows walked once per panel; widths that are not 32 / 64 / 128 / 256 are padded inside the LDS image only).  A wave then needs nobody: it owns a slab of rows, streams X[rows, :] and G[rows, :] through a
+// rows walked once per panel; widths that are not 32 / 64 / 128 / 256 are padded inside the LDS image only).  A wave then needs
+// nobody: it owns a slab of rows, streams X[rows, :] and G[rows, :] through a
 // private LDS ring by LDS-DMA (whole lines, no VGPR staging, RING - 1 stages in flight behind a counted s_waitcnt vmcnt), and per 4 rows
 // reads F / 16 + O / 16 single-word fragments for (F / 16) (O / 16) MFMAs -- no barrier anywhere, nothing recomputed, and shapes narrower
 // than k_wgrad_mfma's 256-feature panel waste nothing.  The LDS image is lane-linear (an LDS-DMA cannot scatter), so the 16-byte pieces

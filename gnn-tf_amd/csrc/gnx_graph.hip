@@ -633,7 +633,8 @@ int gnx_graph_reserve(gnx_graph_t g, int64_t C, int flags, void *stream) {
         if (!g->t_mask && !g->has_dups && g->t.nnz > 0)      // the keep-bit scratch of a training step's column sums
             GNX_HIP(hipMalloc((void **)&g->t_mask, (size_t)g->t.nnz * sizeof(uint16_t)));
     }
-    if ((flags & GNX_RESERVE_K_LOOP) && g->a.order_window == 0 && C <= RELABEL_MAX_C && g->a.n_rows == g->a.n_cols && g->a.n_rows >= (1 << 20) && g->a.nnz >= g->a.n_rows) {
+    if ((flags & GNX_RESERVE_K_LOOP) && g->a.order_window == 0 && C <= RELABEL_MAX_C && g->a.n_rows == g->a.n_cols &&
+        g->a.n_rows >= (1 << 20) && g->a.nnz >= g->a.n_rows) {
         int rc = ensure_relabel(g, s);
         if (rc != GNX_OK) return rc;
         rc = ensure_relabel_features(g, (size_t)g->a.n_rows * (size_t)C * sizeof(float), s);

@@ -347,11 +347,15 @@ int gnx_graph_colsum(gnx_graph_t g, float dropout_p, uint64_t seed, uint64_t str
     if (t.n_rows == 0) return GNX_OK;
     const bool drop = dropout_p > 0.f;
     const unsigned nb = blocks_for(t.n_rows * 8);
-    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, t.long_row, d_colsum_out);
-    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.n_rows, t.long_row, d_colsum_out);
+    if (drop) hipLaunchKernelGGL(k_colsum_short<true>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d,
+                                 t.n_rows, t.long_row, d_colsum_out);
+    else      hipLaunchKernelGGL(k_colsum_short<false>, dim3(nb), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d,
+                                 t.n_rows, t.long_row, d_colsum_out);
     if (t.n_long > 0) {
-        if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
-        else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, t.long_rows, d_colsum_out);
+        if (drop) hipLaunchKernelGGL(k_colsum_long<true>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals,
+                                     g->t_raw, d, t.long_rows, d_colsum_out);
+        else      hipLaunchKernelGGL(k_colsum_long<false>, dim3((unsigned)t.n_long), dim3(256), 0, s, t.rowptr, t.colidx, g->t_perm, g->raw_vals,
+                                     g->t_raw, d, t.long_rows, d_colsum_out);
     }
     GNX_HIP(hipGetLastError());
     return GNX_OK;
@@ -450,8 +454,10 @@ int gnx_graph_scale_values(gnx_graph_t g, float dropout_p, uint64_t seed, uint64
     if (g->a.nnz == 0) return GNX_OK;
     const unsigned nb = blocks_for(g->a.nnz);
     hipStream_t s = (hipStream_t)stream;
-    if (dropout_p > 0.f) hipLaunchKernelGGL(k_scale_values<true>, dim3(nb), dim3(256), 0, s, g->rowidx, g->a.colidx, g->raw_vals, d, d_row_scale, d_col_scale, g->a.nnz, d_vals_out);
-    else                 hipLaunchKernelGGL(k_scale_values<false>, dim3(nb), dim3(256), 0, s, g->rowidx, g->a.colidx, g->raw_vals, d, d_row_scale, d_col_scale, g->a.nnz, d_vals_out);
+    if (dropout_p > 0.f) hipLaunchKernelGGL(k_scale_values<true>, dim3(nb), dim3(256), 0, s, g->rowidx, g->a.colidx, g->raw_vals, d, d_row_scale,
+                                            d_col_scale, g->a.nnz, d_vals_out);
+    else                 hipLaunchKernelGGL(k_scale_values<false>, dim3(nb), dim3(256), 0, s, g->rowidx, g->a.colidx, g->raw_vals, d, d_row_scale,
+                                            d_col_scale, g->a.nnz, d_vals_out);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }
@@ -467,8 +473,10 @@ static int scale_values_any(gnx_graph_t g, bool transposed, float dropout_p, uin
     if (rc != GNX_OK) return rc;
     if (g->a.nnz == 0) return GNX_OK;
     const unsigned nb = blocks_for(g->a.nnz);
-    if (dropout_p > 0.f) hipLaunchKernelGGL(k_scale_values_t<true>, dim3(nb), dim3(256), 0, s, g->t_rowidx, g->t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, rs, cs, g->a.nnz, out);
-    else                 hipLaunchKernelGGL(k_scale_values_t<false>, dim3(nb), dim3(256), 0, s, g->t_rowidx, g->t.colidx, g->t_perm, g->raw_vals, g->t_raw, d, rs, cs, g->a.nnz, out);
+    if (dropout_p > 0.f) hipLaunchKernelGGL(k_scale_values_t<true>, dim3(nb), dim3(256), 0, s, g->t_rowidx, g->t.colidx, g->t_perm, g->raw_vals,
+                                            g->t_raw, d, rs, cs, g->a.nnz, out);
+    else                 hipLaunchKernelGGL(k_scale_values_t<false>, dim3(nb), dim3(256), 0, s, g->t_rowidx, g->t.colidx, g->t_perm, g->raw_vals,
+                                            g->t_raw, d, rs, cs, g->a.nnz, out);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
 }

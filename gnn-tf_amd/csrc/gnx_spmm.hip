@@ -970,7 +970,8 @@ const char *launch_rows(const SpmmArgs &p0, hipStream_t s) {
 template <int VEC>
 const char *launch_rows_and_chunks(const SpmmArgs &p, hipStream_t s) {
     const int lanes = (p.C + VEC - 1) / VEC;
-    if (lanes > 32 || p.n_long == 0 || (p.n_rows >= SMALL_ROWS && !(p.tune & 65536)) || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;   // (65536: tuning builds' A/B of the merged launch on big graphs)
+    // (tune bit 65536: tuning builds' A/B of the merged launch on big graphs)
+    if (lanes > 32 || p.n_long == 0 || (p.n_rows >= SMALL_ROWS && !(p.tune & 65536)) || ((p.tune >> 8) & 3) != 0 || (p.tune & 4096)) return nullptr;
     const unsigned cb = blocks_for(p.n_chunks, 4);
     const char *name;
 #define GNX_BOTH(G, RPB_, PIPE_)                                                                                          \
@@ -1218,7 +1219,8 @@ int gnx_spmm_dropped_chained(gnx_graph_t g, const float *d_D, float dropout_p, u
                              float alpha, int act, float *d_out, int64_t ldo, void *stream) {
     int rc = check_common("gnx_spmm_dropped_chained", g, d_X, ldx, C, d_H0, ldh0, d_out, ldo);
     if (rc != GNX_OK) return rc;
-    GNX_CHECK_ARG((act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_NONE || (act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_RELU, "gnx_spmm_dropped_chained: invalid activation %d", act);
+    GNX_CHECK_ARG((act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_NONE || (act & ~GNX_ACT_SKIP_EMPTY) == GNX_ACT_RELU,
+                  "gnx_spmm_dropped_chained: invalid activation %d", act);
     if (!g->a.empty_rows_unreferenced) act &= ~GNX_ACT_SKIP_EMPTY;       // honoured only when nobody gathers the rows it would leave untouched
     GNX_CHECK_ARG(d_D != nullptr, "gnx_spmm_dropped_chained: NULL degree scales");
     GNX_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "dropout rate %g outside [0, 1)", (double)dropout_p);
@@ -1248,7 +1250,8 @@ int gnx_spmm_dropped_back(gnx_graph_t g, const float *d_D, float dropout_p, uint
     int rc = check_common("gnx_spmm_dropped_back", g, d_X, ldx, C, d_S_in, lds_in, d_S_out, lds_out);
     if (rc != GNX_OK) return rc;
     GNX_CHECK_ARG(act == GNX_ACT_NONE || act == GNX_ACT_SKIP_EMPTY, "gnx_spmm_dropped_back: act must be GNX_ACT_NONE or GNX_ACT_SKIP_EMPTY");
-    GNX_CHECK_ARG(act == GNX_ACT_NONE || (const void *)d_S_in == (const void *)d_S_out, "gnx_spmm_dropped_back: GNX_ACT_SKIP_EMPTY needs the sum updated in place");
+    GNX_CHECK_ARG(act == GNX_ACT_NONE || (const void *)d_S_in == (const void *)d_S_out,
+                  "gnx_spmm_dropped_back: GNX_ACT_SKIP_EMPTY needs the sum updated in place");
     if (rc != GNX_OK) return rc;
     GNX_CHECK_ARG(d_D != nullptr && d_S_in != nullptr, "gnx_spmm_dropped_back: NULL degree scales / running sum");
     GNX_CHECK_ARG(d_Y_out == nullptr || (ldy >= C && (const void *)d_Y_out != (const void *)d_X && (const void *)d_Y_out != (const void *)d_S_out

@@ -11,7 +11,8 @@ from .link_tasks import LinkPrediction, MeanLinkPrediction, negative_sampling, r
 from .sparse import (SparseCOO, DeviceGraph, Adjacency, SparseRows, spmm, spmm_bias_act, ppr_step, ppr_loop, appnp_propagate, gather_rows, normalize,
                      as_coo, dense, sparse_dense, gcnii_step, node_ce, node_argmax, edge_scores)
 from .graph_io import create_nx_graph, adj2graph, graph2indices, graph2adj
-from .graph_model import MLP, GNN, Structural, NGCFLayer, NGCF, PPRIteration, PPRLoop, APPNP, GCNLayer, GCNSpectralPreservingLayer, GCN, GCNIILayer, GCNIISpectralPreservingLayer, GCNII
+from .graph_model import (MLP, GNN, Structural, NGCFLayer, NGCF, PPRIteration, PPRLoop, APPNP, GCNLayer, GCNSpectralPreservingLayer, GCN, GCNIILayer,
+                          GCNIISpectralPreservingLayer, GCNII)
 from .datasets import load_npz, save_npz
 
 __version__ = "0.1.0"

@@ -208,7 +208,8 @@ class PPRIteration(Layer):
         for layer in stack[at + 1:]:
             if not (isinstance(layer, PPRIteration) and layer._plain() and layer.H0 is self.H0 and layer is not self
                     and layer.restart_probability == self.restart_probability and layer.graph_dropout == self.graph_dropout
-                    and (layer.activation is self.activation or (is_relu(layer.activation) and is_relu(self.activation))) and all(layer is not seen for seen in run)):
+                    and (layer.activation is self.activation or (is_relu(layer.activation) and is_relu(self.activation)))
+                    and all(layer is not seen for seen in run)):
                 break
             run.append(layer)
         if len(run) < 2:

@@ -594,7 +594,8 @@ class ShardedGraph:
         ``push_weight`` (cover plans): what a pushed row's entries on the sender weigh against a row on the link
         (cover_push_mask; 0 = fewest rows on the link, larger = fewer and shorter partial sums, more pulled rows).
         ``split_rows``: interior rows (no remote column) as a handle of their own, computed before the halo is
-        waited for -- when they hold at least MIN_INTERIOR_SHARE of the block's entries ("always": whatever they hold).  ``chunks``: independent column chunks whose exchange and SpMM overlap (default 2).
+        waited for -- when they hold at least MIN_INTERIOR_SHARE of the block's entries ("always": whatever they hold).
+        ``chunks``: independent column chunks whose exchange and SpMM overlap (default 2).
         ``keep_entries``: keep (global row, global col, normalised value, pushed?) of this rank's entries in
         ``self.entries`` (tests).  ``relabel`` (single vertex block only): store the shard with its vertices relabelled in stable order of
         descending entry count -- a legal preprocessing step that makes the sub-wave kernels
