@@ -9,7 +9,7 @@
 
 #include "../../include/gnx.h"
 
-#define GNX_VERSION_NUM GNX_ABI_VERSION /* 0.5.0: the header's number */
+#define GNX_VERSION_NUM GNX_ABI_VERSION /* 0.6.0: the header's number */
 
 namespace gnx {
 

@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 500          # include/gnx.h GNX_ABI_VERSION: the header this binding was written against
+ABI_VERSION = 600          # include/gnx.h GNX_ABI_VERSION: the header this binding was written against
 # GNX_LIBRARY: another build of the same library (the tuning build of tools/, `make TUNING=1` -> lib/tune/libgnx.so)
 LIB_PATH = os.environ.get("GNX_LIBRARY") or os.path.join(os.path.dirname(_HERE), "lib", "libgnx.so")
 

@@ -51,8 +51,9 @@ const char *gnx_last_error(void);
  * gnx_version() of the library it loaded and refuses a mismatch in major or minor: entry points changed argument lists under
  * the same names between 0.2 and 0.3 (gnx_halo_plan_create / _layout / _pack / _exchange gained `part` and split pull / push
  * counts; gnx_gcnii_step's d_work became d_mixed), so a 0.2 client linked against a 0.3+ library passes shifted arguments.
- * 0.4 adds gnx_graph_reserve and changes no existing signature; 0.5 adds gnx_graph_set_row_window, likewise. */
-#define GNX_ABI_VERSION 500
+ * 0.4 adds gnx_graph_reserve and changes no existing signature; 0.5 adds gnx_graph_set_row_window, 0.6 gnx_appnp_propagate_act,
+ * likewise. */
+#define GNX_ABI_VERSION 600
 int gnx_version(void);
 
 /* ---- graph construction ------------------------------------------------------------

@@ -215,6 +215,16 @@ def check_case(s):
             else:        # odd widths run the loop at a padded row width: other kernel variants, other summation grouping on hub rows
                 spread = float(np.sqrt(max(np.bincount(idx[:, 0]).max(), 1)))
                 assert torch.allclose(got, H, rtol=1e-5, atol=2e-6 * spread), f"kloop case {case}: {float((got - H).abs().max())}"
+            # the same loop with relu in every iteration's epilogue (filter.py:22,28,35) against K single steps with the relu flag
+            H = dev(H0)
+            for _ in range(K):
+                H = _launch(adj, H, dev(H0), 0.85, 0.15, 1)
+            got = gnntf.appnp_propagate(adj, dev(H0), 0.15, K, relu=True)
+            if gnntf.sparse.friendly_width(C, n) == C:
+                assert torch.equal(got, H), f"relu kloop case {case}"
+            else:
+                spread = float(np.sqrt(max(np.bincount(idx[:, 0]).max(), 1)))
+                assert torch.allclose(got, H, rtol=1e-5, atol=2e-6 * spread), f"relu kloop case {case}: {float((got - H).abs().max())}"
             return "kloop"
         if kind == 3 and nnz:
             adj = gnntf.normalize(g, "symmetric")

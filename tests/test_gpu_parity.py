@@ -273,6 +273,15 @@ def test_k_loop_on_the_relabelled_copy_for_narrow_widths(gnntf):
             else:
                 assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
                 assert torch.equal(got[int(n * 0.75):], H[int(n * 0.75):])           # rows without entries: exactly a * H0
+        if C <= 16:       # the same loop with relu in every iteration's epilogue (gnx_appnp_propagate_act), on the relabelled copy
+            from gnntf import _native as nat
+            for K in (2, 5):
+                H = H0
+                for _ in range(K):
+                    H = gnntf.sparse._launch(adj, H, H0, 0.85, 0.15, nat.ACT_RELU)
+                got = gnntf.appnp_propagate(adj, H0, a=0.15, iterations=K, relu=True)
+                assert torch.allclose(got, H, rtol=2e-5, atol=2e-6), (C, K, float((got - H).abs().max()))
+                assert torch.equal(got[int(n * 0.75):], torch.relu(H0[int(n * 0.75):] * 0.15)) and float(got.min()) >= 0
     del g, adj
     # the same pattern made symmetric: rows without entries are referenced by nobody, and the loop then writes them by its last
     # (scattering) iteration only -- never into a work buffer
