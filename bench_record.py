@@ -135,8 +135,11 @@ def add_gather_ceiling(rec, yard):
 
 # ---- the stdout line --------------------------------------------------------------------------------------------------------
 def sig(x, digits=6):
-    """Numbers of the stdout line: 6 significant digits are beyond what any timing here resolves, and a third of the bytes."""
+    """Numbers of the stdout line: 6 significant digits are beyond what any timing here resolves, and a third of the bytes.  A value
+    that is not finite becomes null: json.dumps would print NaN / Infinity, which a strict parser refuses."""
     if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
         return float(f"{x:.{digits}g}")
     return x
 
@@ -224,7 +227,7 @@ def fit_line(result, limit=LINE_LIMIT):
         if keys:
             dropped.append(f"{where}.{prefix}*")
             line["config"]["dropped_from_line"] = dropped
-    text = json.dumps(line)
+    text = json.dumps(line, allow_nan=False)
     if len(text) > limit:
         raise SystemExit(f"bench.py: the JSON line is {len(text)} bytes, above the {limit} it may have")
     return text

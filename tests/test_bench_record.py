@@ -360,6 +360,16 @@ def test_a_line_that_would_not_fit_sheds_blocks_in_a_fixed_order(traffic_table):
         bench_record.fit_line(dict(result, unknown_block={f"k{i}": 1.0 * i for i in range(2000)}))
 
 
+def test_the_line_is_strict_json(traffic_table):
+    """A NaN or an infinity anywhere in the record would make json.dumps print a token strict parsers refuse: they become null."""
+    result = full_record_with_stand_in_numbers(traffic_table)
+    result["roofline"]["config4_graph_C7_no_reuse_gather_frac"] = float("nan")
+    result["config"]["self_check"]["max_rel_err"] = float("inf")
+    text = bench_record.fit_line(result)
+    line = json.loads(text, parse_constant=lambda token: pytest.fail("non-standard JSON token " + token))
+    assert line["roofline"]["config4_graph_C7_no_reuse_gather_frac"] is None and line["config"]["self_check"]["max_rel_err"] is None
+
+
 def test_median_of_the_timed_steps():
     s = bench_record.step_statistics([5.0, 1.0, 3.0, 100.0])
     assert s == {"median": 4.0, "min": 1.0, "max": 100.0, "mean": 27.25, "n": 4}
