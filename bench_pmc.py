@@ -72,12 +72,17 @@ def fabric_bytes_by_segment(fetch_csv, write_csv, marker="k_stream"):
 def training_launches(g, C, a, K, device):
     """The two launches one training iteration consists of at width ``C`` (a middle forward iteration = gnx_spmm_dropped_chained, a
     middle backward iteration = gnx_spmm_dropped_back over the transposed structure), as closures over their operands: what the
-    segments pass counts and bench_secondary times.  Returns (forward, backward, keep-alive)."""
+    segments pass counts and bench_secondary times.  The operands have the row width the training loop really launches at
+    (sparse.friendly_width: C = 7 runs as 8 with a zero column, 16-byte loads) -- the byte model is still priced at C.
+    Returns (forward, backward, keep-alive)."""
     import torch
     from gnntf import sparse as sp
     n = g.n_rows
-    X = torch.rand(n, C, device=device) * 2 - 1
-    gout = torch.rand(n, C, device=device)
+    Cp = sp.friendly_width(C, n)
+    X = torch.zeros(n, Cp, device=device)
+    X[:, :C] = torch.rand(n, C, device=device) * 2 - 1
+    gout = torch.zeros(n, Cp, device=device)
+    gout[:, :C] = torch.rand(n, C, device=device)
     scales = sp.dropped_degree_scales(g, 0.5, 1, 0, K)
     adj1 = sp.dropped_adjacency(g, 0.5, 1, 1, D=scales[1])
     S_run, Y_run = torch.zeros_like(gout), torch.empty_like(gout)

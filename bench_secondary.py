@@ -273,6 +273,7 @@ def training_step(ctx):
         out[f"training_step_C{C}"] = {"ms": ms, "two_pass_ms": ms2, "edges_per_s": 2 * nnz * K / ms * 1e3,
                                       "forward_launch_ms": ms_f, "backward_launch_ms": ms_b, "degree_scales_all_streams_ms": ms_d,
                                       "launches_share_of_step": (K * (ms_f + ms_b) + ms_d) / ms, "kept_entries": kept, "kernel": kernel_f,
+                                      "launched_at_width": gnntf.sparse.friendly_width(C, n),
                                       "roofline": roof_f, "roofline_backward": roof_b,
                                       "what": f"forward + backward of {K} PPR iterations with per-iteration edge dropout 0.5 + renormalisation, "
                                               f"config-4 graph, C={C}; ms: weights produced inside the SpMM (gnx_spmm_dropped), two_pass_ms: "

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 CSV output (gpurun_out/...) into the small files committed under profiles/.
 
-    python profiles/summarize.py <tag> <stats_dir> [<fetch_dir> <write_dir>] [--workload NAME]
+    python profiles/summarize.py <tag> <stats_dir> [<fetch_dir> <write_dir>] [--workload NAME] [--only REGEX]
+
+--only: count only the SpMM kernels whose short name matches (C = 7: `bench.py --feats 7` runs the layer path, which pads 7 to 8
+and launches the VEC = 4 kernels, AND the C entry at 7 floats per row, the VEC = 1 kernels -- `--only "<1,"` keeps the latter, which
+is what the in-run segments pass measures under this workload's name).
 
 Writes profiles/<tag>_kernel_stats.csv (top kernels of `rocprofv3 --kernel-trace --stats`) and, when
 the two PMC passes are given, profiles/<tag>_pmc.csv plus this workload's entry of profiles/pmc_traffic.json
@@ -34,10 +38,13 @@ def short(name):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    workload = None
+    workload = only = None
     if "--workload" in sys.argv:
         workload = sys.argv[sys.argv.index("--workload") + 1]
         args = [a for a in args if a != workload]
+    if "--only" in sys.argv:
+        only = sys.argv[sys.argv.index("--only") + 1]
+        args = [a for a in args if a != only]
     tag, stats_dir = args[0], args[1]
     rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "**", "*_kernel_stats.csv")))))
     with open(os.path.join(HERE, f"{tag}_kernel_stats.csv"), "w") as f:
@@ -50,7 +57,7 @@ def main():
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for d in args[2:4]:
         for r in csv.DictReader(open(one(os.path.join(d, "**", "*_counter_collection.csv")))):
-            if "k_spmm" in r["Kernel_Name"]:
+            if "k_spmm" in r["Kernel_Name"] and (only is None or re.search(only, short(r["Kernel_Name"]))):
                 k = short(r["Kernel_Name"])
                 per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 per[k]["ms"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)

@@ -1327,6 +1327,12 @@ def test_k_loop_with_relu_in_the_epilogue(gnntf, C):
             assert float(got.min()) >= 0.0
             empty = got[100:400].cpu().numpy()
             np.testing.assert_array_equal(empty, np.maximum(np.float32(0.15) * H0[100:400], 0))
+    # with a diagonal (add_eye, gnn.py:38-39,48-49) the settled-row rule is off and the relu still applies to every row
+    for eye in ("before", "after"):
+        adj_eye = gnntf.normalize(g, "symmetric", eye)
+        got = gnntf.appnp_propagate(adj_eye, dev(H0), a=0.15, iterations=4, relu=True)
+        want = orc.appnp_propagate(coo, vals, shape, H0, a=0.15, iterations=4, add_eye=eye, activation=orc.relu)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
     # and the plain loop is still the plain loop
     assert torch.equal(gnntf.appnp_propagate(adj, dev(H0), a=0.15, iterations=3), gnntf.appnp_propagate(adj, dev(H0), a=0.15, iterations=3, relu=False))
     lib = nat.lib()
