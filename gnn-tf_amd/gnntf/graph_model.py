@@ -160,7 +160,7 @@ class PPRIteration(Layer):
     A RUN of such layers as user code builds it (reference demos/custom_layers.py:8-13: ``for _ in range(10):
     gnn.add(PPRIteration(H0, 0.1))``) executes as one fused loop when the layers are plain -- the same H0 layer, one float restart
     probability, the identity or relu as the activation of ALL of them (relu runs in the kernels' epilogue, gnx_appnp_propagate_act),
-    identity restart transform, no feature dropout, one graph_dropout -- and the run starts from
+    identity restart transform, no feature dropout (in eval mode, where it does not act, any), one graph_dropout -- and the run starts from
     H0's own value: the same arithmetic and the same sequence of edge-dropout masks as layer by layer (bitwise on graphs below
     2^20 vertices; above, narrow widths run on the relabelled copy: float32 rounding), at the cost of the PPRLoop layer.  The last
     layer of the run holds the result; the ``.value`` of an intermediate layer is computed when somebody reads it.
@@ -194,19 +194,22 @@ class PPRIteration(Layer):
     def value(self, v):
         self.__dict__["_value"], self.__dict__["_pending_value"] = v, None
 
-    def _plain(self):
+    def _plain(self, training=True):
+        """Whether this layer can be one step of a fused run.  Feature dropout (filter.py:22) only acts in training mode
+        (layered.py:44-45): an eval-mode run fuses whatever the layers' ``dropout`` says."""
         a = self.restart_probability
         return (type(self) is PPRIteration and isinstance(a, (int, float)) and not isinstance(a, bool)
                 and (self.activation is linear or is_relu(self.activation))
-                and self.restart_transform is linear and self.dropout == 0 and self.output_regularize == 0)
+                and self.restart_transform is linear and (self.dropout == 0 or not training) and self.output_regularize == 0)
 
     def __run__(self, architecture: GNN, features, stack, at):
-        if not self._plain() or not isinstance(architecture, GNN) or features is not getattr(self.H0, "value", None) \
+        training = not isinstance(architecture, GNN) or architecture.is_training()
+        if not self._plain(training) or not isinstance(architecture, GNN) or features is not getattr(self.H0, "value", None) \
                 or not isinstance(features, torch.Tensor) or not features.is_cuda:
             return None
         run = [self]
         for layer in stack[at + 1:]:
-            if not (isinstance(layer, PPRIteration) and layer._plain() and layer.H0 is self.H0 and layer is not self
+            if not (isinstance(layer, PPRIteration) and layer._plain(training) and layer.H0 is self.H0 and layer is not self
                     and layer.restart_probability == self.restart_probability and layer.graph_dropout == self.graph_dropout
                     and (layer.activation is self.activation or (is_relu(layer.activation) and is_relu(self.activation)))
                     and all(layer is not seen for seen in run)):

@@ -1391,6 +1391,30 @@ def test_appnp_with_relu_activation_runs_fused(gnntf):
     assert any(float(gr.abs().max()) > 0 for gr in grads[0])
     for gf, gp in zip(grads[0], grads[1]):
         np.testing.assert_allclose(gf.cpu().numpy(), gp.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # feature dropout (filter.py:22) acts in training mode only: an eval-mode run of layers that have it still fuses; in training
+    # mode the same stack runs layer by layer (torch's generator draws the masks)
+    gnntf.set_seed(7)
+    drop = gnntf.GNN(gnntf.SparseCOO(coo, vals, shape), X)
+    H0 = drop.add(gnntf.Dense(7, regularize=False))
+    for k in range(5):
+        drop.add(gnntf.PPRIteration(H0, 0.1, activation=gnntf.relu, dropout=0.3))
+    drop.reset(); drop.training_mode(False)
+    calls, steps = [], []
+    gnntf.sparse.appnp_propagate = lambda *a, **k: (calls.append(1), real_loop(*a, **k))[1]
+    gnntf.sparse.ppr_step = lambda *a, **k: (steps.append(1), real_step(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            got = drop(drop.features)
+            assert calls == [1] and not steps
+            drop.fuse_runs = False
+            assert torch.equal(got, drop(drop.features)) and len(steps) == 5
+            drop.fuse_runs = True
+        steps.clear()
+        with drop:
+            out = drop(drop.features)
+        assert len(steps) == 5 and out.shape == got.shape                  # training mode: layer by layer
+    finally:
+        gnntf.sparse.appnp_propagate, gnntf.sparse.ppr_step = real_loop, real_step
     # a run whose layers disagree about the activation is not ONE run: relu x 3 then identity x 3 = two fused calls
     gnntf.set_seed(7)
     mixed = gnntf.GNN(gnntf.SparseCOO(coo, vals, shape), X)
