@@ -232,7 +232,9 @@ struct PerDeviceOnce {
     void set(int dev) { if (dev >= 0 && dev < 64) done.fetch_or(uint64_t(1) << dev, std::memory_order_release); }
 };
 
-int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);
+int launch_spmm(gnx_graph *g, const Csr &m, SpmmArgs &p, hipStream_t s);                      // gnx_spmm.hip
+void launch_long_rows(const SpmmArgs &p, hipStream_t s);                                       // gnx_spmm.hip: long rows only
+const char *launch_spmm_dropped(const SpmmArgs &p, int vec, bool has_long, hipStream_t s);    // gnx_spmm_train.hip
 // out[out_rows[r]] = act(X[in_rows[r]] . W + bias) on the matrix cores (gnx_dense.hip); row maps optional
 int dense_rows(const float *X, int64_t ldx, int64_t n, int64_t F, const float *W, int64_t ldw, int64_t O, const float *bias, int act,
                const int32_t *in_rows, const int32_t *out_rows, float *out, int64_t ldo, hipStream_t s);

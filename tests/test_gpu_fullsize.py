@@ -84,7 +84,7 @@ def test_config4_full_size_eigenvector(gnntf):
     g, adj, _ = bench.build_single(argparse.Namespace(nodes=10_000_000, entries=100_000_000), torch.device("cuda:0"))
     assert g.n_rows == 10_000_000 and g.nnz == 100_000_000
     eigenvector_check(gnntf, g, adj, 256)
-    assert g.last_kernel() == "spmm_group4"
+    assert g.last_kernel() == "spmm_group8"
 
 
 def test_config5_full_size_eigenvector(gnntf):

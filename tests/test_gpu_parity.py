@@ -817,7 +817,7 @@ def test_row_window_remaps_the_group_kernels_bitwise(gnntf, n):
     """what reorder="locality" ships at narrow widths is k_spmm_group with the XCD-chunked block remap (xcd_block) over a
     PADDED grid, reached through launch_rows -- a graph without long rows (launch_rows_and_chunks bypasses the remap) and with at
     least 64 windows of non-empty rows.  Every row holds 3 ... 40 entries here, n is prime (the grid is no multiple of 8 chunks), and
-    window = 64 / 96 must return bit for bit what the default order returns at every sub-wave width (group4 ... group32), for a
+    window = 64 / 96 must return bit for bit what the default order returns at every sub-wave width (group8 ... group32), for a
     single step, the K loop with settled rows trimmed, the transposed launch and a training launch."""
     rng = np.random.default_rng(n)
     deg = rng.integers(3, 41, size=n)
@@ -842,7 +842,7 @@ def test_row_window_remaps_the_group_kernels_bitwise(gnntf, n):
             out[C, "drop"] = gnntf.sparse._launch(gnntf.sparse.dropped_adjacency(g, 0.5, 3, 1), H0, H0, 0.9, 0.1, 0)
         return out
     base = everything()
-    assert kernels == {7: "spmm_group8", 8: "spmm_group4", 12: "spmm_group4", 40: "spmm_group16", 64: "spmm_group16", 128: "spmm_group32"}, kernels
+    assert kernels == {7: "spmm_group8", 8: "spmm_group8", 12: "spmm_group8", 40: "spmm_group16", 64: "spmm_group16", 128: "spmm_group32"}, kernels
     for window in (64, 96):
         assert g.n_rows - int((deg == 0).sum()) >= 64 * window            # the remap's own gate (GNX_ROW_PIECES)
         g.set_row_window(window)
