@@ -362,6 +362,8 @@ const char *launch_rows_and_chunks(const SpmmArgs &p, hipStream_t s) {
     if (lanes > 16)     { GNX_BOTH(32, 8, false); name = "spmm_group32+chunks"; }
     else if (lanes > 8) { GNX_BOTH(16, 16, false); name = "spmm_group16+chunks"; }
     else if (lanes > 4) { GNX_BOTH(8, 32, true); name = "spmm_group8+chunks"; }
+    // (rows of up to 4 lanes keep 4-lane groups HERE: the group width is also how a chunk's entries are dealt to sub-groups, i.e. the
+    //  long rows' summation order, which the training kernels of the same width reproduce bit for bit; these launches are latency-bound)
     else                { GNX_BOTH(4, 64, true); name = "spmm_group4+chunks"; }
 #undef GNX_BOTH
     GNX_LAUNCH((k_spmm_long_reduce<VEC>), blocks_for(p.n_long, 4), p);

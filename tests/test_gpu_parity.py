@@ -150,7 +150,7 @@ def test_random_shapes_against_oracle(gnntf):
             want = np.maximum(want, 0)
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-4, err_msg=f"case {case}: {n_rows}x{n_cols} nnz={nnz} C={C} pad={pad}")
         kernels.add(g.last_kernel())
-    assert {k.split("+")[0] for k in kernels} >= {"spmm_wave", "spmm_group32", "spmm_group16", "spmm_group8", "spmm_group4"}
+    assert {k.split("+")[0] for k in kernels} >= {"spmm_wave", "spmm_group32", "spmm_group16", "spmm_group8"}      # (8 lanes per row is the narrowest group)
 
 
 # ---- A2: get_adjacency -------------------------------------------------------------------------------
