@@ -12,7 +12,7 @@
 //     (C = 256: 64 x float4 = the whole 1 KiB row).  The row's (col, val) pairs are fetched 64 at a
 //     time with one coalesced load and broadcast from registers with v_readlane, and U = 8 neighbour
 //     rows are kept in flight per wave before the first FMA;
-//   * narrow features: G = 4..32 lanes per row, 64/G rows per wave, rows taken in a degree-binned
+//   * narrow features: G = 8..32 lanes per row, 64/G rows per wave, rows taken in a degree-binned
 //     order (Csr::row_order) so that the rows sharing a wave have similar lengths; for G <= 8 the next
 //     (col, val) batch is prefetched behind the gathers;
 //   * power-law rows: a row with more than p.long_row entries is cut into p.long_chunk-entry chunks summed

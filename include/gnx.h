@@ -395,7 +395,7 @@ int gnx_stream_read(const float *d_src, int64_t n_floats, float *d_sink64, void 
 int gnx_probe_block_xcd(int64_t n_blocks, int32_t *d_xcd_out, void *stream);
 
 /* Name of the SpMM kernel the last gnx_spmm/_t call on this handle dispatched (static
- * string; for profiles and tests): "spmm_wave", "spmm_group4" ... "spmm_group32" (lanes per row), "..._drop" (weights made
+ * string; for profiles and tests): "spmm_wave", "spmm_group8" ... "spmm_group32" (lanes per row; "spmm_group4+chunks": the merged small-graph launch), "..._drop" (weights made
  * in the kernel), "...+chunks" (structures below 2^20 rows: the chunks of the long rows share the launch of the short rows),
  * "spmm_gcnii_mfma", "spmm+dense_mfma". */
 const char *gnx_graph_last_kernel(gnx_graph_t g);
