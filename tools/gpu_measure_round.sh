@@ -24,7 +24,7 @@ for l in open('$O/cover_sweep_p$P.jsonl'):
   exit 0
 fi
 if [ "$1" != "skip-profiles" ]; then bash tools/gpu_profile_set.sh || exit 1; fi
-O=gpurun_out/${SET:-r5g}_train
+O=gpurun_out/${SET:-r6g}_train
 mkdir -p $O
 rm -rf $O/train_stats $O/train_fetch $O/train_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -o run -- python3 tools/train_roofline.py > $O/train_under_stats.json 2> $O/train_stats.err || { echo "train stats failed"; exit 1; }
@@ -32,7 +32,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/train_fet
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/train_write -o run -- python3 tools/train_roofline.py > $O/train_write.json 2> $O/train_write.err || { echo "train write failed"; exit 1; }
 find $O -name "*_kernel_trace.csv" -size +20M -delete
 echo "train passes done"
-O=gpurun_out/${SET:-r5g}_blocks
+O=gpurun_out/${SET:-r6g}_blocks
 mkdir -p $O
 for cfg in "8 cover 2" "8 cover 4" "8 pull 2" "4 cover 2" "2 cover 2"; do
   set -- $cfg; P=$1; COVER=$2; CH=$3
@@ -44,5 +44,5 @@ for cfg in "8 cover 2" "8 cover 4" "8 pull 2" "4 cover 2" "2 cover 2"; do
   done
   echo "$T done: $(tail -c 200 $O/${T}_FETCH_SIZE.json)"
 done
-for P in 2 4 8; do timeout -k 10 300 python3 tools/sim_blocks.py --world $P > gpurun_out/${SET:-r5g}_blocks/sim_blocks_p$P.json 2> gpurun_out/${SET:-r5g}_blocks/sim_blocks_p$P.err || { echo "sim $P failed"; exit 1; }; done
+for P in 2 4 8; do timeout -k 10 300 python3 tools/sim_blocks.py --world $P > gpurun_out/${SET:-r6g}_blocks/sim_blocks_p$P.json 2> gpurun_out/${SET:-r6g}_blocks/sim_blocks_p$P.err || { echo "sim $P failed"; exit 1; }; done
 echo "all done"

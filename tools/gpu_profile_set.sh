@@ -2,9 +2,9 @@
 # The round's profile set -- kernel stats + FETCH_SIZE / WRITE_SIZE passes (each in a run of its own) of the headline command and of
 # the config-4 graph at the widths SURVEY 8(d) names and the widths gnntf's APPNP propagates (40, 7), then kernel stats of the FULL
 # default bench.  Summaries: profiles/summarize.py, profiles/full_stats.py.
-#   gpurun --timeout 1200 -- 'SET=r5g bash tools/gpu_profile_set.sh'
+#   gpurun --timeout 1200 -- 'SET=r6p bash tools/gpu_profile_set.sh'
 export TMPDIR=/tmp
-SET=${SET:-r5g}
+SET=${SET:-r6g}
 mkdir -p gpurun_out/$SET
 
 profile_one() {      # TAG [bench args]: the three passes of one bench command (no secondary block, no in-run passes, no yardstick graph)
