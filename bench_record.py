@@ -239,9 +239,10 @@ def write_detail(detail, n_gpus):
     name = f"bench_detail_n{n_gpus}.json"
     try:
         with open(os.path.join(ROOT, name), "w") as f:
-            json.dump(detail, f, indent=1)
+            json.dump(detail, f, indent=1, default=str)       # (whatever is not JSON goes in as text: the detail file must never cost the line)
         return name
-    except OSError:
+    except Exception as error:                                # read-only checkout, full disk, ...: the line is printed without it
+        note(f"detail file not written: {error!r}")
         return None
 
 
