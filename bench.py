@@ -319,6 +319,16 @@ def main():
             roof = roofline_record(n_local, nnz_local, C_local, t_c, K, block_name, measured_peak,
                                    what="rank 0's vertex block, one iteration's kernels alone (pack + SpMM of every column chunk; no exchange beside them)")
         detail = {"roofline": roof, "halo": halo, "pmc_in_run": pmc_notes, "alt_grid_feature_slices": alt, "step_ms": step_ms}
+
+        def optional(what, fn, default=None):
+            """What follows the timed region must never cost the headline its line: a part that fails is recorded and left out."""
+            try:
+                return fn()
+            except Exception as error:
+                deadline.dropped.append(f"{what} failed: {error!r}"[:200])
+                note(f"{what} failed and is left out: {error!r}")
+                torch.cuda.empty_cache()
+                return default
         cpu = None
         if not sharded_path and args.cpu_seconds > 0:
             from bench_cpu import cpu_baseline
@@ -327,7 +337,9 @@ def main():
                 deadline.dropped.append(f"cpu_baseline sample shortened to {args.cpu_seconds:.0f} s")
             note("CPU baselines (C / OpenMP port, scipy on one thread, torch.sparse on all threads; bounded samples)")
             t_ph = time.time()
-            cpu = cpu_baseline(s.g, s.adj, s.H0, args)
+            g_, adj_, H0_ = s.g, s.adj, s.H0
+            cpu = optional("cpu_baseline", lambda: cpu_baseline(g_, adj_, H0_, args))
+            del g_, adj_, H0_
             phase("cpu_baseline", t_ph)
         detail["cpu_baseline"] = cpu
         flat = {}
@@ -342,14 +354,15 @@ def main():
                 from bench_secondary import gather_yardstick
                 note("no-reuse gather yardstick (d-regular random graph of the same N and C)")
                 t_ph = time.time()
-                yard = gather_yardstick(device, args.nodes, [C], a)[C]
+                yard = optional("gather yardstick", lambda: gather_yardstick(device, args.nodes, [C], a)[C])
                 br.add_gather_ceiling(roof, yard)
                 detail["no_reuse_gather_yardstick"] = yard
                 phase("gather_yardstick", t_ph)
             if not args.no_secondary and deadline.room(40.0, "secondary workloads"):
                 from bench_secondary import secondary_workloads
                 t_ph = time.time()
-                detail["secondary"], flat = secondary_workloads(args, device, measured_peak, skip_config4=args.workload == "config4", deadline=deadline)
+                detail["secondary"], flat = optional("secondary workloads", lambda: secondary_workloads(
+                    args, device, measured_peak, skip_config4=args.workload == "config4", deadline=deadline), default=({}, {}))
                 phase("secondary_workloads", t_ph)
         else:
             kernel, api = kernel_blocks, None

@@ -412,7 +412,14 @@ def secondary_workloads(args, device, measured_peak, skip_config4=False, deadlin
             continue
         t0 = time.time()
         br.note("secondary: " + name)
-        d, f = table[name]()
+        try:
+            d, f = table[name]()
+        except Exception as error:                               # one part failing must not take the others' results with it
+            br.note(f"secondary: {name} failed and is left out: {error!r}")
+            if deadline is not None:
+                deadline.dropped.append(f"secondary: {name} failed: {error!r}"[:200])
+            torch.cuda.empty_cache()
+            continue
         detail.update(d)
         flat.update(f)
         br.PHASES["secondary_" + name] = round(time.time() - t0, 2)
