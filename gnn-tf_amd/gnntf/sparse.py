@@ -6,6 +6,7 @@ gnntf/core/gnn/architectures/gcn.py:88).
 """
 from __future__ import annotations
 
+import math
 from ctypes import byref, c_float, c_int64, c_void_p
 
 import numpy as np
@@ -423,16 +424,31 @@ PAD_WIDTHS = True      # tools flip this for A/B runs
 PAD_MIN_ROWS = 1 << 16      # smaller graphs are launch-bound: the pad / slice launches would cost more than the loads save
 
 
+def lines_per_row(C: int) -> float:
+    """Average number of 128-byte lines a row of C floats touches when rows are stored back to back (row r starts at byte 4 C r)."""
+    size, step = 4 * C, math.gcd(4 * C, 128)
+    offsets = range(0, 128, step)
+    return sum((off + size + 127) // 128 for off in offsets) / len(offsets)
+
+
 def friendly_width(C: int, n_rows: int = PAD_MIN_ROWS) -> int:
     """The row width (floats) the K-iteration loops run at.  A gather moves whole 128-byte lines and the kernels load 16 bytes
     per lane when rows are 16-byte aligned: rows of 7 ... 31 floats are padded to the next power of two (a row then never
     straddles a line it does not fill: C = 9 ... 15 run 26 % faster as 16, 20 ... 24 as 32), wider ones to the next multiple of
-    4 (C = 41 or 47 -- odd class counts -- would otherwise fall back to 4-byte loads).  The pad columns are zero and stay zero."""
+    4 (C = 41 or 47 -- odd class counts -- would otherwise fall back to 4-byte loads) -- and on to the first multiple of 4 up to
+    the next multiple of 32 at which a row touches no more lines than its size needs (round 6: C = 56, 224-byte rows, half of which
+    span three lines: 4.50 ms per iteration on the config-4 graph against 3.75 as 64; 44 -> 48, 52 / 56 / 60 -> 64; 40 and 48
+    stay, their rows never span a third line).  The pad columns are zero and stay zero."""
     if not PAD_WIDTHS or C <= 6 or n_rows < PAD_MIN_ROWS:     # up to 6 floats the pad / un-pad copies cost what the wider loads save
         return C
     if C <= 32:
         return 1 << (C - 1).bit_length()
-    return (C + 3) // 4 * 4
+    Cp = (C + 3) // 4 * 4
+    best = Cp
+    for wider in range(Cp + 4, (Cp + 31) // 32 * 32 + 1, 4):
+        if lines_per_row(wider) < lines_per_row(best) - 1e-9:
+            best = wider
+    return best
 
 
 def _padded(H: torch.Tensor, Cp: int) -> torch.Tensor:

@@ -334,3 +334,22 @@ def test_custom_splits_follow_the_reference_recipe():
         assert train == want_train and valid == rest[:k] and test == rest[k:]
         assert len(train) == 4 * per_class and not set(train) & set(valid) and not set(valid) & set(test)
         assert all(labels[i] != -1 for i in train + valid + test) and len(train + valid + test) == int((labels != -1).sum())
+
+
+def test_row_widths_of_the_k_loops_fill_their_lines():
+    """sparse.friendly_width: the width the K-iteration loops run at -- 16-byte aligned rows, and no row touching more 128-byte lines
+    than its size needs (lines_per_row: average over the start offsets back-to-back rows take)."""
+    from gnntf.sparse import friendly_width, lines_per_row
+    n = 1 << 20
+    assert [friendly_width(C, n) for C in (1, 6, 7, 8, 9, 16, 17, 24, 32)] == [1, 6, 8, 8, 16, 16, 32, 32, 32]
+    assert lines_per_row(8) == 1.0 and lines_per_row(32) == 1.0 and lines_per_row(24) == 1.5        # 96-byte rows: every other one straddles
+    assert lines_per_row(40) == 2.0 and lines_per_row(48) == 2.0 and lines_per_row(64) == 2.0        # 160 / 192 / 256 bytes: never a third line
+    assert lines_per_row(44) == 2.25 and lines_per_row(56) == 2.5 and lines_per_row(60) == 2.75
+    assert [friendly_width(C, n) for C in (33, 36, 40, 41, 44, 47, 48, 49, 52, 56, 60, 63, 64)] == [36, 36, 40, 48, 48, 48, 48, 64, 64, 64, 64, 64, 64]
+    assert [friendly_width(C, n) for C in (65, 72, 96, 100, 120, 128, 129, 256, 300)] == [68, 72, 96, 100, 128, 128, 132, 256, 304]
+    for C in range(1, 400):
+        Cp = friendly_width(C, n)
+        assert Cp >= C and (C <= 6 or Cp % 4 == 0) and Cp <= max(32, (C + 31) // 32 * 32)
+        if C > 6:
+            assert lines_per_row(Cp) <= lines_per_row((C + 3) // 4 * 4) + 1e-12                      # never more lines than the plain multiple of 4
+    assert friendly_width(56, 1000) == 56                                                              # small graphs: launch-bound, no padding
