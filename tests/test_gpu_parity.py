@@ -1175,7 +1175,7 @@ def test_linear_combination_one_pass(gnntf, n, k):
         linear_combination([(dev(arrays[0]), 1.0)] * 17)
 
 
-@pytest.mark.parametrize("C", [7, 9, 21, 41, 127])
+@pytest.mark.parametrize("C", [7, 9, 21, 41, 56, 127])
 def test_fused_loops_pad_odd_widths(gnntf, C):
     """The K-iteration loops run odd widths at a friendlier row width (power of two up to 32, multiple of 4 beyond; zero pad
     columns): same numbers as the unpadded run to float32 rounding, eval loop and training loop (forward and dH0)."""
