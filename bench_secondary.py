@@ -282,6 +282,32 @@ def training_step(ctx):
                                               f"value of EVERY entry, a neighbour row per KEPT entry, H0 + out + scales per row)"}
         torch.cuda.empty_cache()
     flat["train_kept_entries"] = kept
+    # the same step with the vertices in the model-level degree order (GNN(reorder="degree"), an opt-in: results agree to float32
+    # rounding): the training kernels walk the caller's numbering, so hub rows that are neighbours in memory pay here (NOTES round 6)
+    rowptr, colidx, _ = g.csr_arrays()
+    deg = rowptr[1:] - rowptr[:-1]
+    order = torch.argsort(deg, descending=True, stable=True)
+    newid = torch.empty_like(order)
+    newid[order] = torch.arange(n, device=device)
+    rows = torch.repeat_interleave(torch.arange(n, device=device), deg)
+    idx = torch.stack([newid[rows], newid[colidx.long()]], 1)
+    del rows, rowptr, colidx, deg, order, newid
+    gd = gnntf.DeviceGraph(gnntf.SparseCOO(idx, torch.ones(idx.shape[0], device=device), (n, n)), device=device)
+    del idx
+    for C in (TRAIN_WIDTHS[-1], TRAIN_WIDTHS[1]):
+        H0 = (torch.rand(n, C, device=device) * 2 - 1).requires_grad_()
+        gout = torch.rand(n, C, device=device)
+
+        def step():
+            H0.grad = None
+            scales = gnntf.sparse.dropped_degree_scales(gd, 0.5, 1, 0, K)
+            gnntf.ppr_loop(lambda k, bwd=False: gnntf.sparse.dropped_adjacency(gd, 0.5, 1, k, D=scales[k]), H0, a, K).backward(gout)
+        ms = median_ms(step, reps=3, warm=1)
+        out[f"training_step_C{C}"]["degree_order_ms"] = ms
+        flat[f"train_C{C}_step_degree_order_ms"] = ms
+        del H0, gout
+    del gd
+    torch.cuda.empty_cache()
     return out, flat
 
 

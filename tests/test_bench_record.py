@@ -263,6 +263,8 @@ def full_record_with_stand_in_numbers(traffic_table, n_gpus=1):
                                         b_min=bench.min_bytes_dropped_iteration(n4, e4, W, d == "backward"), what="x" * 300)
             flat.update(bench_record.triple(f"train_C{W}_{d}", rec))
         flat[f"train_C{W}_step_ms"] = 123.456789123
+        if W != 64:
+            flat[f"train_C{W}_step_degree_order_ms"] = 101.23456789
     for W in (256, 8):
         flat.update({f"config4_C{W}_via_layers_ms": 142.123456789, f"config4_C{W}_c_entry_ms": 142.023456789, f"config4_C{W}_layers_bitwise_equal_c_entry": True})
     flat.update(config4_C8_relu_fused_forward_ms=16.123456, config4_C8_relu_layer_by_layer_forward_ms=31.123456, config4_C8_relu_fused_max_abs_diff=2.3841858e-07,
