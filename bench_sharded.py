@@ -77,6 +77,8 @@ class BlockOps:
         self.idx, self.vals, self.bounds, self.comm, self.H0 = idx, vals, bounds, comm, H0
         self.chunk_options, self.a, self.K = chunk_options, a, K
         self.graphs, self.plan_s, self.plan_peak_bytes = {}, {}, None
+        # ranks that share this rank's card (rehearsals: several gloo ranks on one GPU): they all draw on the same free memory
+        self.sharers = max(1, -(-dist.get_world_size() // max(torch.cuda.device_count(), 1))) if dist.is_initialized() else 1
         self.t0 = time.perf_counter()
 
     def agree(self, ok, what, fatal=False):
@@ -115,7 +117,7 @@ class BlockOps:
         torch = self.torch
         if self.plan_peak_bytes is not None:
             free = torch.cuda.mem_get_info(self.device)[0] + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-            if not self.agree(free >= 1.2 * self.plan_peak_bytes, f"memory for the {cover} plan", fatal=fatal):
+            if not self.agree(free >= 1.5 * self.plan_peak_bytes * self.sharers, f"memory for the {cover} plan", fatal=fatal):
                 note(f"the {cover} plan is not built: not enough free device memory on some rank")
                 return False
         t0 = time.time()
